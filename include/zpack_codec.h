@@ -1,0 +1,170 @@
+/*
+ * zpack_codec.h — the thin C-ABI between the ZPack host library and the MI355X entry codec.
+ *
+ * This is the INWARD drop-in boundary: every third-party codec call the reference
+ * makes on the per-entry hot path is replaced by one of the entry points below.  Plain C, plain
+ * pointers and sizes, no torch / HIP types in any signature (streams travel as void*).
+ *
+ *   reference call site (file:line under /root/reference)              replaced by
+ *   ------------------------------------------------------------------ ---------------------------
+ *   lib/zpack_read.c:350-468   switch(comp_method){memcpy |            zpk_codec_decode_batch_device
+ *        ZSTD_decompressDCtx :380 | LZ4F_decompress loop :414-439}      zpk_codec_decode_batch_host
+ *        + XXH3_64bits verify :466-468, guards :328-332                 (one descriptor per entry)
+ *   lib/zpack_write.c:161-224  zpack_compress_file {memcpy |            zpk_codec_encode_batch_device
+ *        ZSTD_compressCCtx :179 | LZ4F_compressBegin/Update/End         zpk_codec_encode_batch_host
+ *        :204-210} + XXH3_64bits :256
+ *   lib/zpack_write.c:125-150  zpack_get_compress_bound                 zpk_codec_compress_bound
+ *   lib/zpack_read.c:466, lib/zpack_write.c:256  XXH3_64bits            zpk_codec_hash_batch_device / _host
+ *   lib/zpack_read.c:17-31,776-812; lib/zpack_write.c:20-34,899-935     zpk_codec_create / _destroy / _reset
+ *        ZSTD_createDCtx / LZ4F_createDecompressionContext / ...        (one opaque context for every method)
+ *   lib/zpack_stream.c:4-28 XXH3 state; zpack_read.c:515-640;           zpk_dstream_* / zpk_cstream_*
+ *        zpack_write.c:461-685 streaming calls                          (chunk aggregation over the batch codec)
+ *
+ * Status values are `enum zpack_result` codes (zpack.h): the device evaluates the same guards in the
+ * same order as zpack_read_file, so `results[i].status` is exactly what zpack_read_file would have
+ * returned for entry i, and one bad entry never poisons the batch.
+ *
+ * There is NO CPU fallback behind this interface: if no HIP device is usable, zpk_codec_create fails
+ * with ZPK_E_NO_DEVICE and every zpack.h call that needs the codec returns ZPACK_ERROR_NOT_AVAILABLE.
+ */
+#ifndef ZPACK_CODEC_H
+#define ZPACK_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZPK_CODEC_ABI_VERSION 1
+
+/* return codes of the zpk_* entry points themselves (not per-entry statuses) */
+enum {
+    ZPK_OK = 0,
+    ZPK_E_NO_DEVICE = -1,      /* no usable HIP device / runtime */
+    ZPK_E_INVALID = -2,        /* bad argument */
+    ZPK_E_NOMEM = -3,          /* host or device allocation failed */
+    ZPK_E_LAUNCH = -4          /* HIP launch / copy error (hipGetLastError text via zpk_codec_last_error) */
+};
+
+/* compression methods — values of zpack_compression_method (zpack.h) */
+enum { ZPK_METHOD_NONE = 0, ZPK_METHOD_ZSTD = 1, ZPK_METHOD_LZ4 = 2 };
+
+typedef struct zpk_codec zpk_codec;
+
+/* One entry to decode.  Mirrors zpack_file_entry (lib/zpack.h:71-80) + the (buffer, max_size) pair of
+ * zpack_read_file (lib/zpack.h:383).  `src_offset` is entry->offset: a byte offset into the archive
+ * image `src` handed to the batch call (whose size plays reader->file_size in the :331 guard). */
+typedef struct zpk_decode_desc {
+    uint64_t src_offset;
+    uint64_t comp_size;
+    uint64_t uncomp_size;
+    uint64_t expect_hash;
+    uint64_t dst_offset;       /* byte offset of this entry's output slot inside `dst` */
+    uint64_t dst_capacity;     /* max_size */
+    uint32_t method;
+    uint32_t flags;            /* ZPK_DF_* */
+} zpk_decode_desc;
+
+#define ZPK_DF_SKIP_HASH 1u    /* decode only; results[i].hash is still produced, status ignores it */
+
+typedef struct zpk_decode_result {
+    int32_t  status;           /* enum zpack_result */
+    uint32_t detail;           /* codec-specific error detail (what the reference keeps in last_return) */
+    uint64_t produced;         /* bytes written to the slot */
+    uint64_t hash;             /* XXH3-64 of dst[0, uncomp_size) — what zpack_read.c:466 computes */
+} zpk_decode_result;
+
+typedef struct zpk_encode_desc {
+    uint64_t src_offset;       /* plaintext offset inside `src` */
+    uint64_t size;
+    uint64_t dst_offset;       /* output slot offset inside `dst` */
+    uint64_t dst_capacity;
+    uint32_t method;
+    int32_t  level;
+} zpk_encode_desc;
+
+typedef struct zpk_encode_result {
+    int32_t  status;
+    uint32_t detail;
+    uint64_t comp_size;
+    uint64_t hash;             /* XXH3-64 of the plaintext (lib/zpack_write.c:256) */
+} zpk_encode_result;
+
+/* ---- context lifecycle -------------------------------------------------------------------- */
+int         zpk_codec_abi_version(void);
+int         zpk_codec_device_count(void);
+/* device: HIP ordinal, or -1 for "env ZPACK_AMD_DEVICE, else LOCAL_RANK, else 0" */
+int         zpk_codec_create(zpk_codec** out, int device);
+void        zpk_codec_destroy(zpk_codec* c);
+void        zpk_codec_reset(zpk_codec* c);                  /* after an abandoned stream / error */
+const char* zpk_codec_last_error(const zpk_codec* c);
+int         zpk_codec_device(const zpk_codec* c);
+
+/* ---- batch decode + verify ----------------------------------------------------------------
+ * Device-resident form: every pointer is a DEVICE pointer on the codec's device; work is enqueued on
+ * `stream` (a hipStream_t passed as void*, NULL = the codec's own stream) and the call returns without
+ * synchronising.  `src` is the archive image (or any packed frame stream), `n` descriptors. */
+int zpk_codec_decode_batch_device(zpk_codec* c, const uint8_t* src, uint64_t src_size,
+                                  const zpk_decode_desc* desc, uint64_t n,
+                                  uint8_t* dst, uint64_t dst_size,
+                                  zpk_decode_result* results, void* stream);
+
+/* Host form: host pointers, synchronous.  Stages [min src_offset, max src_offset+comp_size) of
+ * `archive` to the device, decodes, and copies each slot back to dst_ptrs[i] (desc[i].dst_offset is
+ * ignored; desc[i].dst_capacity is the size of dst_ptrs[i]).  zpack_read_file is a batch of one. */
+int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t archive_size,
+                                const zpk_decode_desc* desc, uint64_t n,
+                                uint8_t* const* dst_ptrs, zpk_decode_result* results);
+
+/* ---- batch encode + hash ------------------------------------------------------------------ */
+size_t zpk_codec_compress_bound(uint32_t method, size_t src_size);
+int zpk_codec_encode_batch_device(zpk_codec* c, const uint8_t* src, uint64_t src_size,
+                                  const zpk_encode_desc* desc, uint64_t n,
+                                  uint8_t* dst, uint64_t dst_size,
+                                  zpk_encode_result* results, void* stream);
+int zpk_codec_encode_batch_host(zpk_codec* c, const uint8_t* const* src_ptrs,
+                                const zpk_encode_desc* desc, uint64_t n,
+                                uint8_t* const* dst_ptrs, zpk_encode_result* results);
+
+/* ---- hash only ---------------------------------------------------------------------------- */
+/* hashes[i] = XXH3_64bits(src + offsets[i], sizes[i]); device pointers, async on stream */
+int zpk_codec_hash_batch_device(zpk_codec* c, const uint8_t* src, const uint64_t* offsets,
+                                const uint64_t* sizes, uint64_t n, uint64_t* hashes, void* stream);
+int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64_t* hash);
+
+/* ---- timing helper for benchmarks: elapsed device time of everything enqueued between the two
+ * marks on `stream`, measured with HIP events on that stream ------------------------------- */
+int zpk_codec_timer_start(zpk_codec* c, void* stream);
+int zpk_codec_timer_stop(zpk_codec* c, void* stream, float* elapsed_ms);   /* synchronises the stop event */
+
+/* ---- streaming triple (lib/zpack_read.c:515-640, lib/zpack_write.c:461-685) ------------------
+ * Chunk granularity is hostile to the GPU, so a stream AGGREGATES: compressed input is collected until
+ * the entry is complete, decoded in one batch-of-one on the device, and the output is then handed out
+ * in avail_out-sized pieces.  Same observable protocol as the reference (total_in/total_out/read_back). */
+typedef struct zpk_dstream zpk_dstream;
+int  zpk_dstream_create(zpk_codec* c, zpk_dstream** out);
+void zpk_dstream_reset(zpk_dstream* s);
+void zpk_dstream_destroy(zpk_dstream* s);
+/* feed in_size bytes, receive up to out_cap bytes; *consumed / *produced report progress;
+ * entry_* describe the entry being streamed; *done = 1 once every output byte has been delivered and
+ * the hash verified.  Returns an enum zpack_result code. */
+int  zpk_dstream_step(zpk_dstream* s, uint32_t method, uint64_t entry_comp_size, uint64_t entry_uncomp_size,
+                      uint64_t entry_hash, const uint8_t* in, size_t in_size, size_t* consumed,
+                      uint8_t* out, size_t out_cap, size_t* produced, int* done);
+
+typedef struct zpk_cstream zpk_cstream;
+int  zpk_cstream_create(zpk_codec* c, zpk_cstream** out);
+void zpk_cstream_reset(zpk_cstream* s);
+void zpk_cstream_destroy(zpk_cstream* s);
+int  zpk_cstream_update(zpk_cstream* s, const uint8_t* in, size_t in_size);       /* collect plaintext */
+/* compress everything collected; the frame is then drained with zpk_cstream_drain */
+int  zpk_cstream_finish(zpk_cstream* s, uint32_t method, int32_t level, uint64_t* comp_size,
+                        uint64_t* uncomp_size, uint64_t* hash);
+size_t zpk_cstream_drain(zpk_cstream* s, uint8_t* out, size_t out_cap);           /* returns bytes copied */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZPACK_CODEC_H */

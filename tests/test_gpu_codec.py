@@ -1,0 +1,170 @@
+"""GPU parity tests: the HIP codec (through the C-ABI of include/zpack_codec.h) against the oracle and
+the golden fixtures written by the compiled reference.  Bit-exact: bytes, XXH3-64 and zpack_result."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zpack_amd
+from benchdata import datagen as dg
+from tests import zpk
+from tests._libs import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def codec():
+    return zpack_amd.Codec(0)
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as fh:
+        return json.load(fh)
+
+
+def _desc(entries, caps):
+    d = np.zeros(len(entries), dtype=zpack_amd.DECODE_DESC)
+    for i, (e, cap) in enumerate(zip(entries, caps)):
+        d[i]["src_offset"] = e["offset"]
+        d[i]["comp_size"] = e["comp_size"]
+        d[i]["uncomp_size"] = e["uncomp_size"]
+        d[i]["expect_hash"] = e["hash"]
+        d[i]["dst_capacity"] = cap
+        d[i]["method"] = e["method"]
+    return d
+
+
+def test_hash_all_length_classes(codec):
+    o = oracle()
+    lens = list(range(0, 300)) + [511, 512, 513, 1023, 1024, 1025, 1087, 1088, 1089, 2047, 2048, 2049, 4095, 4096,
+                                   4097, 65535, 65536, 65537, 100003, 262144, 1048576 + 7]
+    for n in lens:
+        d = dg.fill(dg.RANDOM, 5, n, n)
+        assert codec.hash_host(d.tobytes()) == o.xxh3(d), n
+
+
+def test_hash_batch_device_unaligned(codec):
+    import torch
+    o = oracle()
+    blob = dg.fill(dg.RANDOM, 6, 0, 3 << 20)
+    rng = np.random.default_rng(3)
+    n = 500
+    sizes = rng.integers(0, 5000, n).astype(np.uint64)
+    sizes[::7] = rng.integers(240, 70000, len(sizes[::7]))
+    offs = rng.integers(0, (3 << 20) - 70000, n).astype(np.uint64)
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(blob).to(dev)
+    out = torch.zeros(n, dtype=torch.int64, device=dev)
+    codec.hash_batch_device(src, torch.from_numpy(offs.view(np.int64)).to(dev), torch.from_numpy(sizes.view(np.int64)).to(dev), n, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    for i in range(n):
+        assert int(got[i]) == o.xxh3(blob[int(offs[i]):int(offs[i] + sizes[i])]), i
+
+
+@pytest.mark.parametrize("arc", ["archive_none.zpk", "archive_zstd.zpk", "archive_lz4.zpk"])
+def test_reference_bundled_archives(codec, golden_dir, arc):
+    """tests/read_archive.c:21-35 of the reference on its own archives, through the codec ABI."""
+    wd = os.path.join(golden_dir, "ref_workdir")
+    a = open(os.path.join(wd, arc), "rb").read()
+    ents = zpk.parse(a)
+    res, outs = codec.decode_batch_host(a, _desc(ents, [350, 350]))
+    for e, r, out in zip(ents, res, outs):
+        plain = open(os.path.join(wd, e["filename"]), "rb").read()
+        assert r["status"] == 0 and int(r["hash"]) == e["hash"] and int(r["produced"]) == len(plain)
+        assert out[:len(plain)].tobytes() == plain
+
+
+def test_small_archives_written_by_reference(codec, golden_dir):
+    for case in _load(golden_dir, "small_archives.json"):
+        a = bytes.fromhex(case["archive"])
+        ents = zpk.parse(a)
+        res, outs = codec.decode_batch_host(a, _desc(ents, [e["uncomp_size"] for e in ents]))
+        for e, size, r, out in zip(ents, case["sizes"], res, outs):
+            plain = dg.fill(case["cls"], case["seed"], size, size).tobytes()
+            assert r["status"] == 0, (case["label"], case["corpus"], size, r)
+            assert out[:size].tobytes() == plain, (case["label"], case["corpus"], size)
+            if size:
+                assert int(r["hash"]) == e["hash"]
+
+
+def test_recipes_large_frames(codec, golden_dir):
+    recs = _load(golden_dir, "recipes.json")
+    frames, ents, plains = [], [], []
+    off = 10
+    for r in recs:
+        plain = dg.fill(r["cls"], r["seed"], r["index"], r["size"])
+        frame = dg.compress(r["method"], r["level"], plain)
+        assert len(frame) == r["comp_size"] and dg.xxh3(frame) == r["frame_xxh3"]
+        frames.append(frame)
+        ents.append(dict(offset=off, comp_size=len(frame), uncomp_size=r["size"], hash=r["hash"], method=r["method"]))
+        plains.append(plain)
+        off += len(frame)
+    arc = zpk.assemble(frames, [("f%d" % i, e["offset"], e["comp_size"], e["uncomp_size"], e["hash"], e["method"])
+                               for i, e in enumerate(ents)])
+    res, outs = codec.decode_batch_host(arc, _desc(ents, [e["uncomp_size"] for e in ents]))
+    for r, rr, out, plain in zip(recs, res, outs, plains):
+        assert rr["status"] == 0, (r, rr)
+        assert int(rr["hash"]) == r["hash"] and int(rr["produced"]) == r["size"]
+        assert np.array_equal(out, plain), r
+
+
+def test_status_codes_match_reference(codec, golden_dir):
+    sc = _load(golden_dir, "status_cases.json")
+    for c in sc["cases"]:
+        a = bytearray(bytes.fromhex(sc["bases"][c["base"]]))
+        for p, x in c["flips"]:
+            a[p] ^= x
+        e = zpk.parse(a)[c["index"]]
+        for k, v in c["tamper"].items():
+            e[{"comp_method": "method"}.get(k, k)] = v
+        res, outs = codec.decode_batch_host(bytes(a), _desc([e], [c["max_size"]]))
+        assert int(res[0]["status"]) == c["rc"], (c["label"], res[0], c["rc"])
+        if c["rc"] == 0:
+            assert dg.xxh3(outs[0]) == c["out_xxh3"], c["label"]
+
+
+def test_foreign_frames_match_reference(codec, golden_dir):
+    for c in _load(golden_dir, "foreign_frames.json"):
+        fr = bytes.fromhex(c["frame"])
+        e = dict(offset=10, comp_size=len(fr), uncomp_size=c["uncomp_size"], hash=c["hash"], method=c["method"])
+        arc = zpk.assemble([fr], [("f", 10, len(fr), c["uncomp_size"], c["hash"], c["method"])])
+        res, outs = codec.decode_batch_host(arc, _desc([e], [c["max_size"]]))
+        assert int(res[0]["status"]) == c["rc"], (c["label"], res[0])
+        if c["rc"] == 0:
+            assert dg.xxh3(outs[0][:c["uncomp_size"]]) == c["plain_xxh3"], c["label"]
+
+
+@pytest.mark.parametrize("method,level,size,n", [(dg.LZ4, 0, 65536, 512), (dg.ZSTD, 3, 262144, 96), (dg.NONE, 0, 65536, 256),
+                                                 (dg.COIN, 3, None, 600)])
+def test_device_batch_vs_oracle(codec, method, level, size, n):
+    """Device-resident batch (the bench path) on a seeded mixed-class archive: every byte vs the oracle,
+    every hash vs the real xxHash values the generator recorded."""
+    import torch
+    o = oracle()
+    if size is None:
+        b = dg.Batch(n, 1000, 300000, method=method, level=level, seed=7)
+    else:
+        b = dg.Batch(n, size, method=method, level=level, seed=7)
+    desc, total = zpack_amd.decode_descs_from_batch(b)
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(b.archive).to(dev)
+    dst = torch.zeros(total, dtype=torch.uint8, device=dev)
+    ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    dres = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+    codec.decode_batch_device(src, ddesc, n, dst, dres)
+    torch.cuda.synchronize()
+    res = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)
+    out = dst.cpu().numpy()
+    assert (res["status"] == 0).all(), res[res["status"] != 0][:5]
+    assert np.array_equal(res["hash"], b.hashes)
+    assert np.array_equal(res["produced"], b.uncomp_sizes)
+    arc = b.archive.tobytes()
+    for i in range(0, n, max(1, n // 64)):
+        d = desc[i]
+        rc, want, got, h = o.entry_decode(arc, int(d["src_offset"]), int(d["comp_size"]), int(d["uncomp_size"]),
+                                          int(d["expect_hash"]), int(d["method"]), int(d["dst_capacity"]))
+        assert rc == 0
+        assert out[int(d["dst_offset"]):int(d["dst_offset"] + d["uncomp_size"])].tobytes() == want, i

@@ -1,0 +1,78 @@
+"""Build every native piece of the repo for gfx950 (hipcc cross-compiles without a GPU).
+
+  zpack_amd/libzpk_codec.so   HIP kernels + the codec C-ABI (include/zpack_codec.h)
+  zpack_amd/libzpack_amd.so   the zpack.h host library (C) linked against the codec
+  oracle/liboracle.so         CPU restatement (checker, tests only)
+  oracle/_ref/libzpack_ref.so the compiled reference, when /root/reference is present
+  benchdata/libzpkgen.so      synthetic archive generator (tests + bench input)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+CODEC_SO = os.path.join(HERE, "libzpk_codec.so")
+ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
+ARCH = "gfx950"
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc():
+    h = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(h):
+        raise RuntimeError("hipcc not found: the MI355X codec cannot be built")
+    return h
+
+
+def build_codec(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "zpack_codec.h")]
+    if not force and not _newer(CODEC_SO, srcs):
+        return CODEC_SO
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", "-o", CODEC_SO, os.path.join(CSRC, "zpk_codec.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CODEC_SO
+
+
+def build_zpack(force=False, verbose=False):
+    host = os.path.join(HERE, "host")
+    csrcs = sorted(os.path.join(host, f) for f in os.listdir(host) if f.endswith(".c"))
+    deps = csrcs + [os.path.join(ROOT, "include", "zpack.h"), os.path.join(ROOT, "include", "zpack_codec.h"), CODEC_SO]
+    if not force and not _newer(ZPACK_SO, deps):
+        return ZPACK_SO
+    cmd = ["gcc", "-O2", "-g", "-fPIC", "-shared", "-std=c11", "-Wall", "-Wextra", "-D_FILE_OFFSET_BITS=64",
+           "-I" + os.path.join(ROOT, "include"), "-o", ZPACK_SO] + csrcs + \
+          ["-L" + HERE, "-lzpk_codec", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return ZPACK_SO
+
+
+def build_helpers():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "benchdata"), "libzpkgen.so"])
+    if os.path.isdir("/root/reference/lib"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+
+
+def build_all(force=False, verbose=False):
+    build_codec(force, verbose)
+    if os.path.isdir(os.path.join(HERE, "host")):
+        build_zpack(force, verbose)
+    build_helpers()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

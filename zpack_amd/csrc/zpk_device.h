@@ -1,0 +1,78 @@
+// zpk_device.h — shared device-side helpers for the MI355X (gfx950) entry codec kernels.
+// wave = 64 lanes everywhere; every helper that says "uniform" expects the same value in all lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/zpack_codec.h"
+
+namespace zpk {
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int16_t  i16;
+typedef int32_t  i32;
+typedef int64_t  i64;
+
+// enum zpack_result values (include/zpack.h; reference lib/zpack.h:189-218)
+enum : int {
+    R_OK = 0,
+    R_BUFFER_TOO_SMALL = 12,
+    R_DECOMPRESS_FAILED = 13,
+    R_COMPRESS_FAILED = 14,
+    R_FILE_HASH_MISMATCH = 15,
+    R_FILE_OFFSET_INVALID = 16,
+    R_FILE_INCOMPLETE = 17,
+    R_FILE_SIZE_INVALID = 18,
+    R_COMP_METHOD_INVALID = 19,
+};
+
+// codec-internal decode verdicts (mapped to zpack_result by the entry kernels)
+enum : int { D_OK = 0, D_MALFORMED = -1, D_TRUNCATED = -2, D_DST_FULL = -3 };
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// make a wave-uniform value live in an SGPR so the compiler emits scalar control flow
+__device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uni64(u64 v)
+{
+    u32 lo = uni((u32)v), hi = uni((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) { return (T*)uni64((u64)p); }
+
+// unaligned loads/stores: gfx950 runs in unaligned-access mode, hipcc lowers these to single
+// global_load_dword[x2|x4] / ds_read_b32 instructions (checked in the ISA).
+__device__ __forceinline__ u16 ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
+__device__ __forceinline__ u32 ld32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ u64 ld64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+struct __attribute__((packed, aligned(1))) u128 { u64 lo, hi; };
+__device__ __forceinline__ u128 ld128(const u8* p) { u128 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st128(u8* p, u128 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ void st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ void st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
+
+// uniform byte / halfword / word reads: one lane-0 style load broadcast through an SGPR
+__device__ __forceinline__ u32 uld8(const u8* p) { return uni((u32)*p); }
+__device__ __forceinline__ u32 uld16(const u8* p) { return uni((u32)ld16(p)); }
+__device__ __forceinline__ u32 uld32(const u8* p) { return uni(ld32(p)); }
+
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int mask)
+{
+    u32 lo = (u32)__shfl_xor((int)(u32)v, mask, 64);
+    u32 hi = (u32)__shfl_xor((int)(u32)(v >> 32), mask, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// lanes of one wave exchange data through global memory / LDS: the hardware keeps a wave's vector
+// memory operations in order, so a wavefront-scope fence (a compiler barrier, no s_waitcnt) suffices.
+__device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+__device__ __forceinline__ u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ int highbit32(u32 v) { return 31 - __clz((int)v); }      // v != 0
+
+}  // namespace zpk

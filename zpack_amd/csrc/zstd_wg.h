@@ -1,0 +1,720 @@
+// zstd_wg.h — Zstandard frame decode (RFC 8878) for gfx950: one wave64 workgroup per entry.
+//
+// Replaces ZSTD_decompressDCtx as the reference calls it (lib/zpack_read.c:380): every concatenated
+// frame is decoded, skippable frames are skipped, no dictionary.
+//
+// Data layout per workgroup:
+//   LDS   FSE decode tables (LL/ML 512 x 8 B, OF 256 x 8 B), the three predefined tables, the Huffman
+//         table (up to 2^12 x 2 B; persists across blocks for treeless literals), small build scratch
+//   HBM   the entry's output slot doubles as the match window (offsets reach 256 KiB - 2 MiB, larger
+//         than LDS; recently written lines are L2 hits), a 128 KiB literal scratch per workgroup
+// Per block:
+//   literals   Raw: used in place.  RLE: one byte.  Huffman: table built in LDS, the 4 streams are
+//              decoded by 4 lanes, each with a 128-bit register bit container refilled one load ahead
+//   sequences  the backward FSE bitstream is parsed wave-uniformly out of a 256-byte register window
+//              (v_readlane, no memory wait per field), 64 sequences at a time into lane registers,
+//              then executed: literal run + match copy by all 64 lanes, one sequence after another
+#pragma once
+#include "zpk_device.h"
+#include "xxh3_device.h"
+#include "lz4_wave.h"      // ByteWindow, DecodeOut
+
+namespace zpk {
+
+#define ZSTD_WG_THREADS 64
+#define ZSTD_BLOCK_MAX (128u << 10)
+#define ZSTD_LIT_SCRATCH ((128u << 10) + 64)
+#define ZSTD_GRID_MAX 1792            // 7 workgroups per CU (LDS-limited)
+
+struct FseEntry {          // 8 bytes: one LDS read per state transition
+    u16 next_base;         // new_state = next_base + read(nb_bits)
+    u8  nb_bits;
+    u8  add_bits;          // extra bits of the symbol's value
+    u32 base_value;        // LL/ML: value baseline; OF: 1 << code
+};
+
+struct alignas(16) ZstdShared {
+    FseEntry ll[512], ml[512], of[256];
+    FseEntry wt[64];                             // FSE table of the Huffman weights (accuracy log <= 6)
+    FseEntry dll[64], dml[64], dof[32];          // predefined distributions (built once per workgroup)
+    u16 huf[4096];                               // sym | nbits << 8
+    i16 ncount[3][64];
+    u8  spread[3][512];
+    u16 nextc[3][64];
+    u8  weights[256];
+    u32 huf_max_bits;
+    u32 huf_valid;
+    u32 defaults_built;
+};
+
+__device__ __constant__ const u32 Z_LL_BASE[36] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,
+                                                     0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000 };
+__device__ __constant__ const u8 Z_LL_BITS[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
+__device__ __constant__ const u32 Z_ML_BASE[53] = { 3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,
+                                                     35,37,39,41,43,47,51,59,67,83,99,0x83,0x103,0x203,0x403,0x803,0x1003,0x2003,0x4003,0x8003,0x10003 };
+__device__ __constant__ const u8 Z_ML_BITS[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
+                                                    1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 };
+__device__ __constant__ const i16 Z_LL_DEF[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+__device__ __constant__ const i16 Z_ML_DEF[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
+                                                    -1,-1,-1,-1,-1,-1,-1 };
+__device__ __constant__ const i16 Z_OF_DEF[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+
+enum { T_LL = 0, T_OF = 1, T_ML = 2 };
+
+// ---- wave-uniform bit readers over the register window -----------------------------------------
+
+// 64 stream bits starting at bit `bitpos` (may be negative) of the byte stream at `start`, out of the
+// register window (three v_readlane, no memory access unless the window has to move).  Bytes outside
+// [win.lo, win.hi) read as zero.
+__device__ __forceinline__ u64 win_bits64(ByteWindow& win, const u8* start, i64 bitpos, int lane, bool backward)
+{
+    const u8* p = start + (bitpos >> 3);         // floor
+    i64 d = (i64)(p - win.base);
+    if (d < 0 || d > 244) {
+        const u8* nb = backward ? (const u8*)(((u64)p & ~(u64)3) - 240) : p;
+        win.load(nb, lane);
+        d = (i64)(p - win.base);
+    }
+    int i = (int)(d >> 2), t = (int)(d & 3) * 8 + (int)(bitpos & 7);      // t <= 31
+    u32 w0 = (u32)__builtin_amdgcn_readlane((int)win.w, i);
+    u32 w1 = (u32)__builtin_amdgcn_readlane((int)win.w, i + 1);
+    u32 w2 = (u32)__builtin_amdgcn_readlane((int)win.w, i + 2);
+    u64 lo = ((u64)w1 << 32) | w0;
+    return t ? (lo >> t) | ((u64)w2 << (64 - t)) : lo;
+}
+
+// backward bitstream (FSE payloads): bits are consumed from the top down; below bit 0 reads zero
+struct RevBits {
+    const u8* start;
+    i64 pos;           // bits not yet consumed
+    u64 c;             // container: top `avail` bits are stream bits [pos-avail, pos)
+    int avail;
+
+    __device__ __forceinline__ bool init(ByteWindow& win, const u8* p, u64 size, int lane)
+    {
+        if (size == 0) return false;
+        u32 last = uld8(p + size - 1);
+        if (last == 0) return false;
+        start = p;
+        pos = (i64)(size - 1) * 8 + highbit32(last);
+        win.lo = p; win.hi = p + size;
+        win.base = (const u8*)~(u64)0xFFFF;      // force a (re)load on first use
+        avail = 0; c = 0;
+        refill(win, lane);
+        return true;
+    }
+    __device__ __forceinline__ void refill(ByteWindow& win, int lane)
+    {
+        c = win_bits64(win, start, pos - 64, lane, true);     // stream bits [pos-64, pos), top-aligned
+        avail = 64;
+    }
+    // n <= 32
+    __device__ __forceinline__ u32 read(ByteWindow& win, int n, int lane)
+    {
+        if (n > avail) refill(win, lane);
+        u32 v = n ? (u32)(c >> (64 - n)) : 0u;
+        c = n ? c << n : c;          // n <= 32 < 64
+        avail -= n; pos -= n;
+        return v;
+    }
+};
+
+// forward LSB-first reader (FSE table descriptions); bits past the end read zero
+struct FwdBits {
+    const u8* start;
+    u64 bit;
+    __device__ __forceinline__ u32 read(ByteWindow& win, int n, int lane)
+    {
+        u64 w = win_bits64(win, start, (i64)bit, lane, false);
+        u32 v = (u32)w & ((1u << n) - 1u);                      // n <= 16
+        bit += (u64)n;
+        return v;
+    }
+};
+
+// ---- FSE tables ---------------------------------------------------------------------------------
+
+// RFC 8878 4.1.1: normalized counts.  Uniform.  Returns bytes consumed or -1.
+__device__ inline int fse_read_ncount(ByteWindow& win, const u8* src, u64 size, int max_sym, int max_al,
+                                      i16* ncount /*LDS*/, int& nsym, int& al_out, int lane)
+{
+    win.lo = src; win.hi = src + size;
+    win.base = (const u8*)~(u64)0xFFFF;
+    FwdBits b; b.start = src; b.bit = 0;
+    int al = 5 + (int)b.read(win, 4, lane);
+    if (al > max_al) return -1;
+    int remaining = 1 << al;
+    int s = 0;
+    while (remaining > 0 && s <= max_sym) {
+        int nb = highbit32((u32)remaining + 1) + 1;
+        u32 val = b.read(win, nb, lane);
+        u32 lower_mask = (1u << (nb - 1)) - 1;
+        u32 threshold = (1u << nb) - 1 - ((u32)remaining + 1);
+        if ((val & lower_mask) < threshold) { b.bit -= 1; val &= lower_mask; }
+        else if (val > lower_mask) val -= threshold;
+        int proba = (int)val - 1;
+        remaining -= proba < 0 ? 1 : proba;
+        if (lane == 0) ncount[s] = (i16)proba;
+        s++;
+        if (proba == 0) {
+            u32 rep = b.read(win, 2, lane);
+            for (;;) {
+                for (u32 i = 0; i < rep; i++) {
+                    if (s > max_sym) return -1;
+                    if (lane == 0) ncount[s] = 0;
+                    s++;
+                }
+                if (rep != 3) break;
+                rep = b.read(win, 2, lane);
+            }
+        }
+    }
+    if (remaining != 0) return -1;
+    u64 used = (b.bit + 7) >> 3;
+    if (used > size) return -1;
+    nsym = s; al_out = al;
+    return (int)used;
+}
+
+// Build one decode table from normalized counts — executed by ONE lane (three tables are built by
+// three lanes side by side).  kind selects the value tables.  Returns false on a malformed distribution.
+__device__ inline bool fse_build_lane(FseEntry* tab, const i16* ncount, int nsym, int al, int kind, u8* spread, u16* nextc)
+{
+    const int size = 1 << al;
+    int high = size;
+    for (int s = 0; s < nsym; s++)
+        if (ncount[s] == -1) { spread[--high] = (u8)s; nextc[s] = 1; }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        int f = ncount[s];
+        if (f <= 0) continue;
+        nextc[s] = (u16)f;
+        for (int i = 0; i < f; i++) {
+            spread[pos] = (u8)s;
+            do { pos = (pos + step) & mask; } while (pos >= high);
+        }
+    }
+    if (pos != 0) return false;
+    for (int i = 0; i < size; i++) {
+        int s = spread[i];
+        u32 n = nextc[s]++;
+        int nb = al - highbit32(n);
+        FseEntry e;
+        e.nb_bits = (u8)nb;
+        e.next_base = (u16)((n << nb) - (u32)size);
+        if (kind == T_LL) { e.base_value = Z_LL_BASE[s]; e.add_bits = Z_LL_BITS[s]; }
+        else if (kind == T_ML) { e.base_value = Z_ML_BASE[s]; e.add_bits = Z_ML_BITS[s]; }
+        else if (kind == T_OF) { e.base_value = 1u << s; e.add_bits = (u8)s; }
+        else { e.base_value = (u32)s; e.add_bits = 0; }                 // Huffman weights
+        tab[i] = e;
+    }
+    return true;
+}
+
+__device__ __forceinline__ FseEntry fse_rle_entry(int kind, u32 s)
+{
+    FseEntry e; e.next_base = 0; e.nb_bits = 0;
+    if (kind == T_LL) { e.base_value = Z_LL_BASE[s]; e.add_bits = Z_LL_BITS[s]; }
+    else if (kind == T_ML) { e.base_value = Z_ML_BASE[s]; e.add_bits = Z_ML_BITS[s]; }
+    else { e.base_value = 1u << s; e.add_bits = (u8)s; }
+    return e;
+}
+
+__device__ __forceinline__ FseEntry lds_entry(const FseEntry* tab, u32 state)
+{
+    u64 raw = *(const u64*)&tab[state];
+    raw = uni64(raw);
+    FseEntry e; __builtin_memcpy(&e, &raw, 8);
+    return e;
+}
+
+// ---- Huffman ------------------------------------------------------------------------------------
+
+// weights[0..n) are in LDS (n includes the implied last weight).  Whole wave; returns false if malformed.
+__device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
+{
+    // rank counts + weight sum by lane 0 (n <= 256)
+    __shared__ u32 rank_start[16];
+    __shared__ u32 ok_flag;
+    if (lane == 0) {
+        u32 cnt[14];
+        for (int i = 0; i < 14; i++) cnt[i] = 0;
+        u32 sum = 0; bool ok = true;
+        for (int i = 0; i < n; i++) {
+            u32 w = sh.weights[i];
+            if (w > 12) { ok = false; break; }
+            cnt[w]++;
+            if (w) sum += 1u << (w - 1);
+        }
+        int mb = 0;
+        if (ok) {
+            if (sum == 0 || (sum & (sum - 1))) ok = false;
+            else { mb = highbit32(sum); if (mb < 1 || mb > 12) ok = false; }
+        }
+        if (ok && (cnt[1] < 2 || (cnt[1] & 1))) ok = false;          // libzstd HUF_readStats
+        if (ok) {
+            u32 pos = 0;
+            for (int w = 1; w <= mb; w++) { rank_start[w] = pos; pos += cnt[w] << (w - 1); }
+            sh.huf_max_bits = (u32)mb;
+        }
+        ok_flag = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!ok_flag) return false;
+    const int mb = (int)sh.huf_max_bits;
+    // fill: symbols of one weight take consecutive ranges in natural order -> serial over symbols per
+    // weight for the range starts (lane 0), then all lanes fill the ranges
+    __shared__ u16 sym_start[256];
+    if (lane == 0) {
+        u32 st[14];
+        for (int w = 1; w <= mb; w++) st[w] = rank_start[w];
+        for (int i = 0; i < n; i++) {
+            u32 w = sh.weights[i];
+            if (w) { sym_start[i] = (u16)st[w]; st[w] += 1u << (w - 1); }
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < n; i++) {
+        u32 w = sh.weights[i];
+        if (!w) continue;
+        u32 len = 1u << (w - 1), base = sym_start[i];
+        u16 ent = (u16)((u32)i | ((u32)(mb + 1 - (int)w) << 8));
+        for (u32 k = lane; k < len; k += WAVE) sh.huf[base + k] = ent;
+    }
+    __syncthreads();
+    sh.huf_valid = 1;
+    return true;
+}
+
+// RFC 8878 4.2.1 Huffman tree description.  Returns bytes consumed or -1.  Uniform.
+__device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* src, u64 size, int lane)
+{
+    if (size < 1) return -1;
+    const u32 hb = uld8(src);
+    int n = 0;
+    u64 used;
+    if (hb >= 128) {
+        n = (int)hb - 127;
+        u64 bytes = ((u64)n + 1) / 2;
+        if (1 + bytes > size) return -1;
+        for (int i = lane; i < n; i += WAVE) {
+            u8 b = src[1 + i / 2];
+            sh.weights[i] = (i & 1) ? (b & 15) : (b >> 4);
+        }
+        used = 1 + bytes;
+    } else {
+        const u64 csize = hb;
+        if (csize == 0 || 1 + csize > size) return -1;
+        int nsym = 0, al = 0;
+        int tb = fse_read_ncount(win, src + 1, csize, 12, 6, sh.ncount[0], nsym, al, lane);
+        if (tb < 0) return -1;
+        __syncthreads();
+        __shared__ u32 okb;
+        if (lane == 0) okb = fse_build_lane(sh.wt, sh.ncount[0], nsym, al, 3, sh.spread[0], sh.nextc[0]) ? 1u : 0u;
+        __syncthreads();
+        if (!okb) return -1;
+        RevBits b;
+        if (!b.init(win, src + 1 + tb, csize - (u64)tb, lane)) return -1;
+        u32 s1 = b.read(win, al, lane), s2 = b.read(win, al, lane);
+        // two interleaved states; ends when an update over-reads (libzstd FSE_decompress tail)
+        for (;;) {
+            if (n > 253) return -1;
+            FseEntry e1 = lds_entry(sh.wt, s1);
+            if (lane == 0) sh.weights[n] = (u8)e1.base_value;
+            n++;
+            s1 = e1.next_base + b.read(win, e1.nb_bits, lane);
+            if (b.pos < 0) { FseEntry e2 = lds_entry(sh.wt, s2); if (lane == 0) sh.weights[n] = (u8)e2.base_value; n++; break; }
+            if (n > 253) return -1;
+            FseEntry e2 = lds_entry(sh.wt, s2);
+            if (lane == 0) sh.weights[n] = (u8)e2.base_value;
+            n++;
+            s2 = e2.next_base + b.read(win, e2.nb_bits, lane);
+            if (b.pos < 0) { FseEntry e3 = lds_entry(sh.wt, s1); if (lane == 0) sh.weights[n] = (u8)e3.base_value; n++; break; }
+        }
+        used = 1 + csize;
+    }
+    __syncthreads();
+    // implied last weight
+    __shared__ int lastw;
+    if (lane == 0) {
+        u32 sum = 0; bool ok = true;
+        for (int i = 0; i < n; i++) { u32 w = sh.weights[i]; if (w > 12) ok = false; else if (w) sum += 1u << (w - 1); }
+        lastw = -1;
+        if (ok && sum != 0) {
+            int mb = highbit32(sum) + 1;
+            if (mb <= 12) {
+                u32 left = (1u << mb) - sum;
+                if (!(left & (left - 1))) lastw = highbit32(left) + 1;
+            }
+        }
+        if (lastw >= 0) sh.weights[n] = (u8)lastw;
+    }
+    __syncthreads();
+    if (lastw < 0) return -1;
+    if (!huf_build(sh, n + 1, lane)) return -1;
+    return (int)used;
+}
+
+// per-lane backward bit container for the Huffman streams (divergent: each lane its own stream)
+struct LaneBits {
+    const u8* start; const u8* rd_hi;
+    i64 pos;              // bits not yet consumed
+    i64 cb;               // container covers stream bits [cb*8, cb*8 + 128)
+    u64 c_lo, c_hi, pre;  // pre = the 8 bytes below c_lo, loaded one step ahead
+
+    __device__ __forceinline__ u64 fetch(i64 byte) const
+    {
+        const u8* a = start + byte;
+        if (byte >= 0 && a + 8 <= rd_hi) return ld64(a);
+        u64 v = 0;
+        for (int i = 0; i < 8; i++) { i64 bb = byte + i; if (bb >= 0 && start + bb < rd_hi) v |= (u64)start[bb] << (8 * i); }
+        return v;
+    }
+    __device__ __forceinline__ void init(const u8* p, u64 size, const u8* hi, int hb)
+    {
+        start = p; rd_hi = hi;
+        pos = (i64)(size - 1) * 8 + hb;
+        cb = ((pos + 7) >> 3) - 16;
+        c_lo = fetch(cb); c_hi = fetch(cb + 8); pre = fetch(cb - 8);
+    }
+    // bits [bp, bp+n), n <= 12; bp may be negative (zeros below 0)
+    __device__ __forceinline__ u32 peek(i64 bp, int n)
+    {
+        while (bp < cb * 8) { c_hi = c_lo; c_lo = pre; cb -= 8; pre = fetch(cb - 8); }
+        int rel = (int)(bp - cb * 8);
+        u64 v = rel >= 64 ? c_hi >> (rel - 64) : (rel ? (c_lo >> rel) | (c_hi << (64 - rel)) : c_lo);
+        return (u32)v & ((1u << n) - 1u);
+    }
+};
+
+// decode `nstreams` (1 or 4) Huffman streams into lit[0..regen).  Whole wave; lanes 0..nstreams-1 work.
+__device__ inline bool huf_decode_streams(const ZstdShared& sh, const u8* p, u64 size, int nstreams, u8* lit, u64 regen,
+                                          const u8* rd_hi, int lane)
+{
+    const u8* sp = p; u64 ssz = size; u8* out = lit; u64 cnt = regen;
+    bool bad = false;
+    if (nstreams == 4) {
+        if (size < 10) return false;
+        u64 s1 = uld16(p), s2 = uld16(p + 2), s3 = uld16(p + 4);
+        if (6 + s1 + s2 + s3 > size) return false;
+        u64 s4 = size - 6 - s1 - s2 - s3;
+        u64 seg = (regen + 3) / 4;
+        if (seg * 3 > regen) return false;
+        const u8* q = p + 6;
+        if (lane == 0) { sp = q; ssz = s1; out = lit; cnt = seg; }
+        else if (lane == 1) { sp = q + s1; ssz = s2; out = lit + seg; cnt = seg; }
+        else if (lane == 2) { sp = q + s1 + s2; ssz = s3; out = lit + 2 * seg; cnt = seg; }
+        else { sp = q + s1 + s2 + s3; ssz = s4; out = lit + 3 * seg; cnt = regen - 3 * seg; }
+    }
+    if (lane < nstreams) {
+        if (ssz == 0 || sp[ssz - 1] == 0) bad = true;
+        else {
+            const int mb = (int)sh.huf_max_bits;
+            LaneBits b; b.init(sp, ssz, rd_hi, highbit32(sp[ssz - 1]));
+            for (u64 i = 0; i < cnt; i++) {
+                u32 idx = b.peek(b.pos - mb, mb);              // zeros below bit 0
+                u32 e = sh.huf[idx];
+                out[i] = (u8)e;
+                b.pos -= (i64)(e >> 8);
+            }
+            if (b.pos != 0) bad = true;              // libzstd: BIT_endOfDStream required
+        }
+    }
+    return __ballot(bad) == 0;
+}
+
+// ---- one compressed block ------------------------------------------------------------------------
+
+struct ZFrameState {
+    u64 rep0, rep1, rep2;
+    bool seq_tables_valid;
+    int al_ll, al_of, al_ml;
+};
+
+// sequences table for one of LL/OF/ML; returns bytes consumed or -1
+__device__ inline int read_seq_table(ZstdShared& sh, ByteWindow& win, int kind, int mode, const u8* src, u64 size,
+                                     bool have_prev, int& al, int& pending_build, int& nsym_out, int lane)
+{
+    FseEntry* tab = kind == T_LL ? sh.ll : (kind == T_OF ? sh.of : sh.ml);
+    const int max_sym = kind == T_LL ? 35 : (kind == T_OF ? 31 : 52);
+    const int max_al = kind == T_OF ? 8 : 9;
+    if (mode == 0) {
+        const FseEntry* def = kind == T_LL ? sh.dll : (kind == T_OF ? sh.dof : sh.dml);
+        const int n = kind == T_OF ? 32 : 64;
+        for (int i = lane; i < n; i += WAVE) tab[i] = def[i];
+        al = kind == T_OF ? 5 : 6;
+        return 0;
+    }
+    if (mode == 1) {
+        if (size < 1) return -1;
+        u32 s = uld8(src);
+        if ((int)s > max_sym) return -1;
+        if (lane == 0) tab[0] = fse_rle_entry(kind, s);
+        al = 0;
+        return 1;
+    }
+    if (mode == 2) {
+        int nsym = 0, a = 0;
+        int used = fse_read_ncount(win, src, size, max_sym, max_al, sh.ncount[kind], nsym, a, lane);
+        if (used < 0) return -1;
+        al = a; nsym_out = nsym;
+        pending_build |= 1 << kind;
+        return used;
+    }
+    return have_prev ? 0 : -1;
+}
+
+__device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src, u64 size, const u8* rd_hi,
+                                 u8* dst, u64 dst_cap, u8* frame_lo, u8* lit_buf, u64& produced, int lane)
+{
+    ByteWindow win;
+    if (size < 3) return D_MALFORMED;
+    // ---- literals section ----
+    const u32 b0 = uld8(src);
+    const u32 type = b0 & 3, fmt = (b0 >> 2) & 3;
+    const u8* lit = lit_buf; u64 lit_size = 0, used = 0;
+    bool lit_rle = false; u32 lit_rle_byte = 0;
+    if (type < 2) {
+        u64 hl, n;
+        if ((fmt & 1) == 0) { hl = 1; n = b0 >> 3; }
+        else if (fmt == 1) { hl = 2; n = (b0 >> 4) | ((u64)uld8(src + 1) << 4); }
+        else { hl = 3; n = (b0 >> 4) | ((u64)uld8(src + 1) << 4) | ((u64)uld8(src + 2) << 12); }
+        if (n > ZSTD_BLOCK_MAX) return D_MALFORMED;
+        if (type == 0) { if (hl + n > size) return D_MALFORMED; lit = src + hl; used = hl + n; }
+        else { if (hl + 1 > size) return D_MALFORMED; lit_rle = true; lit_rle_byte = uld8(src + hl); used = hl + 1; }
+        lit_size = n;
+    } else {
+        if (size < 5) return D_MALFORMED;
+        u64 hl, regen, csize; int streams;
+        const u64 v = uld32(src);
+        if (fmt == 0) { hl = 3; streams = 1; regen = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
+        else if (fmt == 1) { hl = 3; streams = 4; regen = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
+        else if (fmt == 2) { hl = 4; streams = 4; regen = (v >> 4) & 0x3FFF; csize = v >> 18; }
+        else { hl = 5; streams = 4; regen = (v >> 4) & 0x3FFFF; csize = (v >> 22) | ((u64)uld8(src + 4) << 10); }
+        if (regen > ZSTD_BLOCK_MAX || hl + csize > size) return D_MALFORMED;
+        const u8* p = src + hl; u64 left = csize;
+        if (type == 2) {
+            int t = huf_read_tree(sh, win, p, left, lane);
+            if (t < 0) return D_MALFORMED;
+            p += t; left -= (u64)t;
+        } else if (!sh.huf_valid) return D_MALFORMED;
+        __syncthreads();
+        if (!huf_decode_streams(sh, p, left, streams, lit_buf, regen, rd_hi, lane)) return D_MALFORMED;
+        wave_mem_fence();
+        lit_size = regen; used = hl + csize;
+    }
+    // ---- sequences header ----
+    const u8* p = src + used;
+    u64 left = size - used;
+    if (left < 1) return D_MALFORMED;
+    u64 nseq = uld8(p);
+    if (nseq == 0) { if (left != 1) return D_MALFORMED; p += 1; left -= 1; }
+    else if (nseq < 128) { p += 1; left -= 1; }
+    else if (nseq < 255) { if (left < 2) return D_MALFORMED; nseq = ((nseq - 128) << 8) + uld8(p + 1); p += 2; left -= 2; }
+    else { if (left < 3) return D_MALFORMED; nseq = (u64)uld8(p + 1) + ((u64)uld8(p + 2) << 8) + 0x7F00; p += 3; left -= 3; }
+
+    u8* op = dst; u8* oend = dst + dst_cap;
+    u64 lit_pos = 0;
+    if (nseq > 0) {
+        if (left < 1) return D_MALFORMED;
+        const u32 modes = uld8(p);
+        p += 1; left -= 1;
+        int pending = 0, ns[3] = {0, 0, 0};
+        int r;
+        r = read_seq_table(sh, win, T_LL, (modes >> 6) & 3, p, left, fs.seq_tables_valid, fs.al_ll, pending, ns[T_LL], lane);
+        if (r < 0) return D_MALFORMED;
+        p += r; left -= (u64)r;
+        r = read_seq_table(sh, win, T_OF, (modes >> 4) & 3, p, left, fs.seq_tables_valid, fs.al_of, pending, ns[T_OF], lane);
+        if (r < 0) return D_MALFORMED;
+        p += r; left -= (u64)r;
+        r = read_seq_table(sh, win, T_ML, (modes >> 2) & 3, p, left, fs.seq_tables_valid, fs.al_ml, pending, ns[T_ML], lane);
+        if (r < 0) return D_MALFORMED;
+        p += r; left -= (u64)r;
+        __syncthreads();
+        {   // the FSE-described tables are built side by side, one lane each
+            bool ok = true;
+            if (lane == T_LL && (pending & (1 << T_LL))) ok = fse_build_lane(sh.ll, sh.ncount[T_LL], ns[T_LL], fs.al_ll, T_LL, sh.spread[T_LL], sh.nextc[T_LL]);
+            if (lane == T_OF && (pending & (1 << T_OF))) ok = fse_build_lane(sh.of, sh.ncount[T_OF], ns[T_OF], fs.al_of, T_OF, sh.spread[T_OF], sh.nextc[T_OF]);
+            if (lane == T_ML && (pending & (1 << T_ML))) ok = fse_build_lane(sh.ml, sh.ncount[T_ML], ns[T_ML], fs.al_ml, T_ML, sh.spread[T_ML], sh.nextc[T_ML]);
+            if (__ballot(!ok) != 0) return D_MALFORMED;
+        }
+        __syncthreads();
+        fs.seq_tables_valid = true;
+
+        RevBits b;
+        if (!b.init(win, p, left, lane)) return D_MALFORMED;
+        u32 sll = b.read(win, fs.al_ll, lane);
+        u32 sof = b.read(win, fs.al_of, lane);
+        u32 sml = b.read(win, fs.al_ml, lane);
+        FseEntry ell = lds_entry(sh.ll, sll), eof_ = lds_entry(sh.of, sof), eml = lds_entry(sh.ml, sml);
+
+        for (u64 base = 0; base < nseq; base += WAVE) {
+            const int cnt = (int)(nseq - base < WAVE ? nseq - base : WAVE);
+            u32 my_ll = 0, my_ml = 0; u64 my_off = 0;
+            // ---- C1: parse up to 64 sequences wave-uniformly, sequence k lands in lane k's registers
+            for (int k = 0; k < cnt; k++) {
+                const u32 ofb = eof_.add_bits;
+                u64 of_val = (u64)eof_.base_value + b.read(win, (int)ofb, lane);
+                u32 ml = eml.base_value + b.read(win, eml.add_bits, lane);
+                u32 ll = ell.base_value + b.read(win, ell.add_bits, lane);
+                u64 offset;
+                if (of_val > 3) {
+                    offset = of_val - 3;
+                    fs.rep2 = fs.rep1; fs.rep1 = fs.rep0; fs.rep0 = offset;
+                } else {
+                    u32 idx = (u32)of_val - 1 + (ell.base_value == 0 && ell.add_bits == 0 ? 1u : 0u);
+                    if (idx == 0) offset = fs.rep0;
+                    else {
+                        u64 t = idx == 3 ? fs.rep0 - 1 : (idx == 1 ? fs.rep1 : fs.rep2);
+                        if (t == 0) t = 1;                                   // libzstd: forced to 1 on corrupt input
+                        if (idx != 1) fs.rep2 = fs.rep1;
+                        fs.rep1 = fs.rep0;
+                        fs.rep0 = offset = t;
+                    }
+                }
+                // libzstd 1.4.9 updates all three states after every sequence, the last included
+                sll = ell.next_base + b.read(win, ell.nb_bits, lane);
+                sml = eml.next_base + b.read(win, eml.nb_bits, lane);
+                sof = eof_.next_base + b.read(win, eof_.nb_bits, lane);
+                ell = lds_entry(sh.ll, sll); eml = lds_entry(sh.ml, sml); eof_ = lds_entry(sh.of, sof);
+                if (lane == k) { my_ll = ll; my_ml = ml; my_off = offset; }
+            }
+            // ---- execute the batch in order: literal run, then match, each by all 64 lanes
+            for (int k = 0; k < cnt; k++) {
+                const u64 ll = (u32)__builtin_amdgcn_readlane((int)my_ll, k);
+                const u64 ml = (u32)__builtin_amdgcn_readlane((int)my_ml, k);
+                const u64 off = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(my_off >> 32), k) << 32) |
+                                (u32)__builtin_amdgcn_readlane((int)(u32)my_off, k);
+                if (ll + ml > (u64)(oend - op)) { produced = (u64)(op - dst); return D_DST_FULL; }
+                if (ll > lit_size - lit_pos) return D_MALFORMED;
+                if (lit_rle) { for (u64 i = lane; i < ll; i += WAVE) op[i] = (u8)lit_rle_byte; }
+                else { for (u64 i = lane; i < ll; i += WAVE) op[i] = lit[lit_pos + i]; }
+                op += ll; lit_pos += ll;
+                if (off > (u64)(op - frame_lo)) return D_MALFORMED;
+                wave_mem_fence();
+                const u8* m = op - off;
+                if (off >= ml) { for (u64 i = lane; i < ml; i += WAVE) op[i] = m[i]; }
+                else { for (u64 i = lane; i < ml; i += WAVE) op[i] = m[i % off]; }
+                wave_mem_fence();
+                op += ml;
+            }
+        }
+        if (b.pos > 0) return D_MALFORMED;           // libzstd 1.4.9: the stream must not be under-consumed
+    }
+    const u64 rest = lit_size - lit_pos;
+    if (rest > (u64)(oend - op)) { produced = (u64)(op - dst); return D_DST_FULL; }
+    if (lit_rle) { for (u64 i = lane; i < rest; i += WAVE) op[i] = (u8)lit_rle_byte; }
+    else { for (u64 i = lane; i < rest; i += WAVE) op[i] = lit[lit_pos + i]; }
+    op += rest;
+    wave_mem_fence();
+    if ((u64)(op - dst) > ZSTD_BLOCK_MAX) return D_MALFORMED;
+    produced = (u64)(op - dst);
+    return D_OK;
+}
+
+// ---- frames --------------------------------------------------------------------------------------
+
+__device__ inline void zstd_build_defaults(ZstdShared& sh, int lane)
+{
+    for (int i = lane; i < 36; i += WAVE) sh.ncount[T_LL][i] = Z_LL_DEF[i];
+    for (int i = lane; i < 29; i += WAVE) sh.ncount[T_OF][i] = Z_OF_DEF[i];
+    for (int i = lane; i < 53; i += WAVE) sh.ncount[T_ML][i] = Z_ML_DEF[i];
+    __syncthreads();
+    if (lane == T_LL) fse_build_lane(sh.dll, sh.ncount[T_LL], 36, 6, T_LL, sh.spread[T_LL], sh.nextc[T_LL]);
+    if (lane == T_OF) fse_build_lane(sh.dof, sh.ncount[T_OF], 29, 5, T_OF, sh.spread[T_OF], sh.nextc[T_OF]);
+    if (lane == T_ML) fse_build_lane(sh.dml, sh.ncount[T_ML], 53, 6, T_ML, sh.spread[T_ML], sh.nextc[T_ML]);
+    __syncthreads();
+}
+
+__device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u8* lit_buf, int lane)
+{
+    DecodeOut r; r.rc = D_OK; r.produced = 0;
+    const u8* ip = src; const u8* iend = src + src_size;
+    u8* op = dst; u8* oend = dst + dst_cap;
+    if (!sh.defaults_built) { zstd_build_defaults(sh, lane); sh.defaults_built = 1; }
+    __syncthreads();
+
+    while (ip < iend) {
+        if (iend - ip < 4) { r.rc = D_MALFORMED; break; }
+        const u32 magic = uld32(ip);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+            if (iend - ip < 8) { r.rc = D_MALFORMED; break; }
+            u64 sz = uld32(ip + 4);
+            if ((u64)(iend - ip) - 8 < sz) { r.rc = D_MALFORMED; break; }
+            ip += 8 + sz;
+            continue;
+        }
+        if (magic != 0xFD2FB528u) { r.rc = D_MALFORMED; break; }
+        // ---- frame header ----
+        if (iend - ip < 6) { r.rc = D_MALFORMED; break; }
+        ip += 4;
+        const u32 fhd = uld8(ip++);
+        const u32 fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, cksum = (fhd >> 2) & 1, did_flag = fhd & 3;
+        if (fhd & 0x08) { r.rc = D_MALFORMED; break; }
+        if (!single) {
+            if (iend - ip < 1) { r.rc = D_MALFORMED; break; }
+            const u32 wd = uld8(ip++);
+            if (10 + (wd >> 3) > 31) { r.rc = D_MALFORMED; break; }
+        }
+        const u32 dn = did_flag == 3 ? 4 : did_flag;
+        if ((u64)(iend - ip) < dn) { r.rc = D_MALFORMED; break; }
+        u32 dict_id = 0;
+        for (u32 i = 0; i < dn; i++) dict_id |= uld8(ip + i) << (8 * i);
+        ip += dn;
+        if (dict_id != 0) { r.rc = D_MALFORMED; break; }
+        const u32 fn = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+        if ((u64)(iend - ip) < fn) { r.rc = D_MALFORMED; break; }
+        u64 fcs = 0;
+        for (u32 i = 0; i < fn; i++) fcs |= (u64)uld8(ip + i) << (8 * i);
+        if (fn == 2) fcs += 256;
+        ip += fn;
+
+        ZFrameState fs;
+        fs.rep0 = 1; fs.rep1 = 4; fs.rep2 = 8; fs.seq_tables_valid = false; fs.al_ll = fs.al_of = fs.al_ml = 0;
+        if (lane == 0) sh.huf_valid = 0;
+        __syncthreads();
+        u8* frame_lo = op;
+        bool fail = false;
+        for (;;) {
+            if (iend - ip < 3) { r.rc = D_MALFORMED; fail = true; break; }
+            const u32 bh = uld8(ip) | (uld8(ip + 1) << 8) | (uld8(ip + 2) << 16);
+            ip += 3;
+            const bool last = bh & 1; const u32 type = (bh >> 1) & 3; const u64 bsize = bh >> 3;
+            if (type == 3) { r.rc = D_MALFORMED; fail = true; break; }
+            if (type == 0) {
+                if (bsize > (u64)(iend - ip)) { r.rc = D_MALFORMED; fail = true; break; }
+                if (bsize > (u64)(oend - op)) { r.rc = D_DST_FULL; fail = true; break; }
+                for (u64 i = lane; i < bsize; i += WAVE) op[i] = ip[i];
+                ip += bsize; op += bsize;
+            } else if (type == 1) {
+                if (iend - ip < 1) { r.rc = D_MALFORMED; fail = true; break; }
+                if (bsize > (u64)(oend - op)) { r.rc = D_DST_FULL; fail = true; break; }
+                const u8 v = (u8)uld8(ip);
+                for (u64 i = lane; i < bsize; i += WAVE) op[i] = v;
+                ip += 1; op += bsize;
+            } else {
+                if (bsize > (u64)(iend - ip) || bsize >= ZSTD_BLOCK_MAX) { r.rc = D_MALFORMED; fail = true; break; }
+                u64 got = 0;
+                int rc = zstd_block(sh, fs, ip, bsize, iend, op, (u64)(oend - op), frame_lo, lit_buf, got, lane);
+                if (rc != D_OK) { r.rc = rc; fail = true; break; }
+                ip += bsize; op += got;
+            }
+            wave_mem_fence();
+            if (last) break;
+        }
+        if (fail) break;
+        if (fn != 0 && (u64)(op - frame_lo) != fcs) { r.rc = D_MALFORMED; break; }
+        if (cksum) {
+            if (iend - ip < 4) { r.rc = D_MALFORMED; break; }
+            u32 h = 0;
+            if (lane == 0) h = (u32)xxh64_serial(frame_lo, (u64)(op - frame_lo), 0);
+            if (uni(h) != uld32(ip)) { r.rc = D_MALFORMED; break; }
+            ip += 4;
+        }
+    }
+    r.produced = (u64)(op - dst);
+    return r;
+}
+
+}  // namespace zpk
