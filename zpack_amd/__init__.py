@@ -41,6 +41,12 @@ def lib():
         if not os.path.exists(CODEC_SO):
             raise CodecUnavailable("%s is missing: run `python -m zpack_amd.build` (or __graft_entry__.build()); "
                                    "there is no CPU fallback" % CODEC_SO)
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7; importing it first makes
+        # the dynamic loader resolve this library's libamdhip64.so.7 dependency to the same copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(CODEC_SO)
         vp, u64, u8p = C.c_void_p, C.c_uint64, C.c_void_p
         L.zpk_codec_create.argtypes = [C.POINTER(vp), C.c_int]

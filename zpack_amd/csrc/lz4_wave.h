@@ -48,12 +48,12 @@ struct ByteWindow {
 struct DecodeOut { int rc; u64 produced; };
 
 // one LZ4 block: src [ip, iend) -> dst [op, ...), cap = oend; hist_lo = lowest output address a match may reach
-__device__ inline int lz4_block_wave(ByteWindow& win, const u8* ip, const u8* iend, u8* dst_lo, u8*& op_io, u8* oend, int lane)
+__device__ inline int lz4_block_wave(ByteWindow& win, Watchdog& wd, const u8* ip, const u8* iend, u8* dst_lo, u8*& op_io, u8* oend, int lane)
 {
     u8* op = op_io;
     if (ip >= iend) return D_MALFORMED;
     for (;;) {
-        if (ip >= iend) return D_MALFORMED;
+        if (ip >= iend || wd.expired()) return D_MALFORMED;
         u32 tok = win.byte(ip++, lane);
         u64 lit = tok >> 4;
         if (lit == 15) {
@@ -99,7 +99,7 @@ __device__ inline int lz4_block_wave(ByteWindow& win, const u8* ip, const u8* ie
 }
 
 // whole frame.  src_lo/src_hi bound what may be READ (the archive image); all values uniform.
-__device__ inline DecodeOut lz4f_decode_wave(const u8* src, u64 src_size, const u8* src_lo, const u8* src_hi,
+__device__ inline DecodeOut lz4f_decode_wave(Watchdog& wd, const u8* src, u64 src_size, const u8* src_lo, const u8* src_hi,
                                              u8* dst, u64 dst_cap, int lane)
 {
     DecodeOut r; r.rc = D_OK; r.produced = 0;
@@ -136,6 +136,7 @@ __device__ inline DecodeOut lz4f_decode_wave(const u8* src, u64 src_size, const 
     if (has_cs) content_size = uni64(ld64(ip + 6));
     {
         u32 h = 0;
+        lane0_guard();
         if (lane == 0) h = (xxh32_serial(ip + 4, hdr - 5, 0) >> 8) & 0xFF;
         if (uni(h) != uld8(ip + hdr - 1)) { r.rc = D_MALFORMED; return r; }
     }
@@ -143,6 +144,7 @@ __device__ inline DecodeOut lz4f_decode_wave(const u8* src, u64 src_size, const 
 
     u8* frame_out = op;
     for (;;) {
+        if (wd.expired()) { r.rc = D_MALFORMED; return r; }
         if (iend - ip < 4) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
         const u32 bh = uld32(ip);
         ip += 4;
@@ -163,6 +165,7 @@ __device__ inline DecodeOut lz4f_decode_wave(const u8* src, u64 src_size, const 
         }
         if (bck) {
             u32 h = 0;
+            lane0_guard();
             if (lane == 0) h = xxh32_serial(ip, bsz, 0);
             if (uni(h) != uld32(ip + bsz)) { r.rc = D_MALFORMED; return r; }
         }
@@ -179,7 +182,7 @@ __device__ inline DecodeOut lz4f_decode_wave(const u8* src, u64 src_size, const 
             u8* bend = oend;
             bool limited = false;
             if ((u64)(oend - op) > bmax) { bend = op + bmax; limited = true; }
-            int rc = lz4_block_wave(win, ip, ip + bsz, hist_lo, op, bend, lane);
+            int rc = lz4_block_wave(win, wd, ip, ip + bsz, hist_lo, op, bend, lane);
             if (rc == D_DST_FULL) {
                 if (limited) { r.rc = D_MALFORMED; return r; }
                 r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r;
@@ -192,6 +195,7 @@ __device__ inline DecodeOut lz4f_decode_wave(const u8* src, u64 src_size, const 
     if (cck) {
         if (iend - ip < 4) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
         u32 h = 0;
+        lane0_guard();
         if (lane == 0) h = xxh32_serial(frame_out, (u64)(op - frame_out), 0);
         if (uni(h) != uld32(ip)) { r.rc = D_MALFORMED; return r; }
         ip += 4;

@@ -188,6 +188,7 @@ __device__ inline u64 xxh3_64_wave(const u8* p, u64 len, int lane)
 {
     if (len <= 240) {
         u64 h = 0;
+        lane0_guard();
         if (lane == 0) h = xxh3_short(p, (u32)len);
         return uni64(h);
     }

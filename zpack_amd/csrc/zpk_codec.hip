@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <time.h>
+
 
 #include "zpk_device.h"
 #include "xxh3_device.h"
@@ -55,11 +57,21 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
     }
 }
 
+// persistent-grid dequeue (only k_zstd needs a bounded number of workgroups, for its literal scratch)
 __device__ __forceinline__ bool dequeue(u32* counters, int list, int lane, u32& idx)
 {
+    lane0_guard();
     u32 v = 0;
     if (lane == 0) v = atomicAdd(&counters[L_COUNT + list], 1u);
     idx = uni(v);
+    lane0_guard();
+    return idx < uni(counters[list]);
+}
+
+// one wave per work-list slot: the hardware dispatcher is the load balancer
+__device__ __forceinline__ bool my_slot(const u32* counters, int list, u32& idx)
+{
+    idx = uni((u32)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     return idx < uni(counters[list]);
 }
 
@@ -67,11 +79,13 @@ __device__ __forceinline__ void finish_entry(const zpk_decode_desc& d, zpk_decod
                                              u64 produced, const u8* out, int lane)
 {
     u64 h = 0;
+    lane0_guard();
     if (status == R_OK && !(d.flags & ZPK_DF_SKIP_HASH)) {
         wave_mem_fence();
         h = xxh3_64_wave(out, d.uncomp_size, lane);                            // lib/zpack_read.c:466
         if (h != d.expect_hash) status = R_FILE_HASH_MISMATCH;                 // :467-468
     }
+    lane0_guard();
     if (lane == 0) {
         zpk_decode_result r; r.status = status; r.detail = detail; r.produced = produced; r.hash = h;
         res[e] = r;
@@ -81,11 +95,11 @@ __device__ __forceinline__ void finish_entry(const zpk_decode_desc& d, zpk_decod
 // method 0: copy + hash fused — each 1 KiB block is loaded once, stored, and folded into the hash
 __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                 u8* __restrict__ dst, zpk_decode_result* __restrict__ res,
-                                                const u32* __restrict__ list, u32* __restrict__ counters)
+                                                const u32* __restrict__ list, const u32* __restrict__ counters)
 {
     const int lane = lane_id();
     u32 idx;
-    while (dequeue(counters, L_NONE, lane, idx)) {
+    if (my_slot(counters, L_NONE, idx)) {
         const u32 e = uni(list[idx]);
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
@@ -95,6 +109,7 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
         if (len <= 240) {
             for (u64 i = lane; i < len; i += WAVE) out[i] = in[i];
             h = 0;
+            lane0_guard();
             if (lane == 0) h = xxh3_short(in, (u32)len);
             h = uni64(h);
         } else {
@@ -118,6 +133,7 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
         }
         int status = R_OK;
         if (!(d.flags & ZPK_DF_SKIP_HASH) && h != d.expect_hash) status = R_FILE_HASH_MISMATCH;
+        lane0_guard();
         if (lane == 0) {
             zpk_decode_result r; r.status = status; r.detail = 0; r.produced = len; r.hash = h;
             res[e] = r;
@@ -128,22 +144,23 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
 __global__ __launch_bounds__(256) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
-                                                  u32* __restrict__ counters)
+                                                  const u32* __restrict__ counters)
 {
     const int lane = lane_id();
     u32 idx;
-    while (dequeue(counters, L_LZ4, lane, idx)) {
+    if (my_slot(counters, L_LZ4, idx)) {
         const u32 e = uni(list[idx]);
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
-        DecodeOut o = lz4f_decode_wave(in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
+        Watchdog wd; wd.arm();
+        DecodeOut o = lz4f_decode_wave(wd, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
         // lib/zpack_read.c:421-450
         int status = R_OK;
         if (o.rc == D_MALFORMED) status = R_DECOMPRESS_FAILED;
         else if (o.rc == D_TRUNCATED) status = o.produced < d.dst_capacity ? R_FILE_INCOMPLETE : R_BUFFER_TOO_SMALL;
         else if (o.rc == D_DST_FULL) status = R_BUFFER_TOO_SMALL;
-        finish_entry(d, res, e, status, (u32)(-o.rc), o.produced, out, lane);
+        finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
     }
 }
 
@@ -163,9 +180,10 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS) void k_zstd(const u8* __restrict__
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
-        DecodeOut o = zstd_decode_wave(sh, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane);
+        Watchdog wd; wd.arm();
+        DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane);
         int status = o.rc == D_OK ? R_OK : R_DECOMPRESS_FAILED;               // lib/zpack_read.c:384-388
-        finish_entry(d, res, e, status, (u32)(-o.rc), o.produced, out, lane);
+        finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
     }
 }
 
@@ -173,10 +191,10 @@ __global__ __launch_bounds__(256) void k_hash(const u8* __restrict__ src, const 
                                               const u64* __restrict__ sizes, u64 n, u64* __restrict__ hashes)
 {
     const int lane = lane_id();
-    u64 w = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (; w < n; w += nw) {
+    const u64 w = uni64(((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w < n) {
         u64 h = xxh3_64_wave(uni_ptr(src + offsets[w]), uni64(sizes[w]), lane);
+        lane0_guard();
         if (lane == 0) hashes[w] = h;
     }
 }
@@ -274,16 +292,44 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     const u64 stride = c->list_cap / (3 * sizeof(u32));
     const u32 zstd_grid = (u32)(n < ZSTD_GRID_MAX ? n : ZSTD_GRID_MAX);
     if ((rc = grow(c, (void**)&c->d_lit, &c->lit_cap, (u64)ZSTD_GRID_MAX * ZSTD_LIT_SCRATCH))) return rc;
+    // debugging aids: ZPK_TRACE=1 synchronises and reports after every launch, ZPK_SKIP=<bitmask> leaves
+    // kernels out (1 stored, 2 lz4, 4 zstd)
+    static const int trace = getenv("ZPK_TRACE") ? atoi(getenv("ZPK_TRACE")) : 0;
+    static const int skip = getenv("ZPK_SKIP") ? atoi(getenv("ZPK_SKIP")) : 0;
+    static hipEvent_t tev[8]; static int tev_n = 0; static const char* tev_name[8];
+    if (trace == 2) { tev_n = 0; for (int i = 0; i < 8; i++) if (!tev[i]) (void)hipEventCreate(&tev[i]); }
+#define ZPK_TRACE_STEP(name) do { if (trace == 1) { hipError_t te_ = hipStreamSynchronize(st); \
+        fprintf(stderr, "[zpk] %s done: %s\n", name, hipGetErrorString(te_)); fflush(stderr); } \
+        else if (trace == 2) { tev_name[tev_n] = name; (void)hipEventRecord(tev[tev_n++], st); } } while (0)
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 64, st));
+    ZPK_TRACE_STEP("memset");
     hipLaunchKernelGGL(k_classify, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, desc, n, src_size, dst_size, res,
                        c->d_lists, stride, c->d_counters);
-    const u32 waves = (u32)(n < 8192 ? n : 8192);
-    const u32 wgrid = (waves + 3) / 4;
-    hipLaunchKernelGGL(k_stored, dim3(wgrid), dim3(256), 0, st, src, desc, dst, res, c->d_lists + L_NONE * stride, c->d_counters);
-    hipLaunchKernelGGL(k_lz4_wave, dim3(wgrid), dim3(256), 0, st, src, read_lo, read_hi, desc, dst, res,
+    ZPK_TRACE_STEP("k_classify");
+    const u32 wgrid = (u32)((n + 3) / 4);          // one wave per list slot
+    if (!(skip & 1)) hipLaunchKernelGGL(k_stored, dim3(wgrid), dim3(256), 0, st, src, desc, dst, res, c->d_lists + L_NONE * stride, c->d_counters);
+    ZPK_TRACE_STEP("k_stored");
+    if (!(skip & 2)) hipLaunchKernelGGL(k_lz4_wave, dim3(wgrid), dim3(256), 0, st, src, read_lo, read_hi, desc, dst, res,
                        c->d_lists + L_LZ4 * stride, c->d_counters);
-    hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
+    ZPK_TRACE_STEP("k_lz4_wave");
+    if (!(skip & 4)) hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
                        c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit);
+    ZPK_TRACE_STEP("k_zstd");
+    if (trace == 2) {
+        for (int spin = 0; spin < 100; spin++) {
+            bool all = true;
+            for (int i = 0; i < tev_n; i++) if (hipEventQuery(tev[i]) != hipSuccess) all = false;
+            if (all) break;
+            struct timespec ts = { 0, 100000000 }; nanosleep(&ts, nullptr);
+        }
+        for (int i = 0; i < tev_n; i++)
+            fprintf(stderr, "[zpk] after 10s: %-12s %s\n", tev_name[i], hipEventQuery(tev[i]) == hipSuccess ? "done" : "NOT DONE");
+        u32 hc[16];
+        if (hipEventQuery(tev[tev_n - 1]) != hipSuccess) { fflush(stderr); _Exit(3); }
+        (void)hipMemcpy(hc, c->d_counters, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[zpk] counters: count %u %u %u head %u %u %u\n", hc[0], hc[1], hc[2], hc[4], hc[5], hc[6]);
+        fflush(stderr);
+    }
     HIPCHK(c, hipGetLastError());
     return ZPK_OK;
 }
@@ -326,11 +372,17 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
     if (e != hipSuccess) { free(hd); snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
     // base pointer such that base + src_offset lands in the staged range; reads are clamped to it
     const u8* base = c->d_src - lo;
+    const bool crumbs = getenv("ZPK_TRACE") && atoi(getenv("ZPK_TRACE")) == 3;
+#define CRUMB(msg) do { if (crumbs) { fprintf(stderr, "[zpk] %s\n", msg); fflush(stderr); } } while (0)
+    CRUMB("H2D queued");
     rc = decode_launch(c, base, archive_size, c->d_src, c->d_src + (hi - lo), (const zpk_decode_desc*)c->d_desc, n,
                        c->d_dst, out_total, (zpk_decode_result*)c->d_res, c->stream);
     if (rc) { free(hd); return rc; }
+    CRUMB("kernels queued");
     e = hipMemcpyAsync(results, c->d_res, n * sizeof(zpk_decode_result), hipMemcpyDeviceToHost, c->stream);
+    CRUMB("results D2H queued");
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    CRUMB("stream synchronised");
     if (e != hipSuccess) { free(hd); snprintf(c->err, sizeof(c->err), "decode: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
     // hand the bytes back: everything the codec produced (hash mismatch leaves data in the buffer, like the reference)
     if (n == 1) {
@@ -347,6 +399,7 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
             }
         free(tmp);
     }
+    CRUMB("payload D2H done");
     free(hd);
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "D2H: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
     return ZPK_OK;
@@ -359,8 +412,7 @@ int zpk_codec_hash_batch_device(zpk_codec* c, const uint8_t* src, const uint64_t
     if (n == 0) return ZPK_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    const u32 waves = (u32)(n < 8192 ? n : 8192);
-    hipLaunchKernelGGL(k_hash, dim3((waves + 3) / 4), dim3(256), 0, st, src, offsets, sizes, n, hashes);
+    hipLaunchKernelGGL(k_hash, dim3((u32)((n + 3) / 4)), dim3(256), 0, st, src, offsets, sizes, n, hashes);
     HIPCHK(c, hipGetLastError());
     return ZPK_OK;
 }

@@ -44,6 +44,13 @@ __device__ __forceinline__ u64 uni64(u64 v)
 }
 template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) { return (T*)uni64((u64)p); }
 
+// CONVERGENCE HAZARD (hit on hardware, ROCm 7.2): two `if (lane == 0)` regions with no convergent
+// operation between them get jump-threaded together by LLVM, also across a loop back edge; the loop
+// then runs per-lane-class and a following readfirstlane no longer sees lane 0 (the wave re-processes
+// stale data forever).  Every lane-0 region whose result is broadcast starts behind lane0_guard(): the
+// wave barrier is a convergent no-op, and LLVM never duplicates a block that holds one.
+__device__ __forceinline__ void lane0_guard() { __builtin_amdgcn_wave_barrier(); }
+
 // unaligned loads/stores: gfx950 runs in unaligned-access mode, hipcc lowers these to single
 // global_load_dword[x2|x4] / ds_read_b32 instructions (checked in the ISA).
 __device__ __forceinline__ u16 ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
@@ -70,6 +77,22 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int mask)
 // lanes of one wave exchange data through global memory / LDS: the hardware keeps a wave's vector
 // memory operations in order, so a wavefront-scope fence (a compiler barrier, no s_waitcnt) suffices.
 __device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// Every parse loop polls this: a wave that spends more than ZPK_WATCHDOG_SECONDS on one entry gives the
+// entry up (status DECOMPRESS_FAILED, detail 0xDEAD) instead of holding the GPU — malformed input or a
+// decoder bug must never leave a wave spinning.  s_memrealtime ticks at 100 MHz; polled every 256 steps.
+#ifndef ZPK_WATCHDOG_SECONDS
+#define ZPK_WATCHDOG_SECONDS 4
+#endif
+struct Watchdog {
+    u64 deadline; u32 tick; bool fired;
+    __device__ __forceinline__ void arm() { deadline = __builtin_amdgcn_s_memrealtime() + (u64)ZPK_WATCHDOG_SECONDS * 100000000ull; tick = 0; fired = false; }
+    __device__ __forceinline__ bool expired()
+    {
+        if (((++tick) & 255u) == 0 && __builtin_amdgcn_s_memrealtime() > deadline) fired = true;
+        return fired;
+    }
+};
 
 __device__ __forceinline__ u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
 __device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }

@@ -154,6 +154,7 @@ __device__ inline int fse_read_ncount(ByteWindow& win, const u8* src, u64 size, 
         else if (val > lower_mask) val -= threshold;
         int proba = (int)val - 1;
         remaining -= proba < 0 ? 1 : proba;
+        lane0_guard();
         if (lane == 0) ncount[s] = (i16)proba;
         s++;
         if (proba == 0) {
@@ -161,6 +162,7 @@ __device__ inline int fse_read_ncount(ByteWindow& win, const u8* src, u64 size, 
             for (;;) {
                 for (u32 i = 0; i < rep; i++) {
                     if (s > max_sym) return -1;
+                    lane0_guard();
                     if (lane == 0) ncount[s] = 0;
                     s++;
                 }
@@ -237,6 +239,7 @@ __device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
     // rank counts + weight sum by lane 0 (n <= 256)
     __shared__ u32 rank_start[16];
     __shared__ u32 ok_flag;
+    lane0_guard();
     if (lane == 0) {
         u32 cnt[14];
         for (int i = 0; i < 14; i++) cnt[i] = 0;
@@ -266,6 +269,7 @@ __device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
     // fill: symbols of one weight take consecutive ranges in natural order -> serial over symbols per
     // weight for the range starts (lane 0), then all lanes fill the ranges
     __shared__ u16 sym_start[256];
+    lane0_guard();
     if (lane == 0) {
         u32 st[14];
         for (int w = 1; w <= mb; w++) st[w] = rank_start[w];
@@ -311,6 +315,7 @@ __device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* s
         if (tb < 0) return -1;
         __syncthreads();
         __shared__ u32 okb;
+        lane0_guard();
         if (lane == 0) okb = fse_build_lane(sh.wt, sh.ncount[0], nsym, al, 3, sh.spread[0], sh.nextc[0]) ? 1u : 0u;
         __syncthreads();
         if (!okb) return -1;
@@ -321,12 +326,14 @@ __device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* s
         for (;;) {
             if (n > 253) return -1;
             FseEntry e1 = lds_entry(sh.wt, s1);
+            lane0_guard();
             if (lane == 0) sh.weights[n] = (u8)e1.base_value;
             n++;
             s1 = e1.next_base + b.read(win, e1.nb_bits, lane);
             if (b.pos < 0) { FseEntry e2 = lds_entry(sh.wt, s2); if (lane == 0) sh.weights[n] = (u8)e2.base_value; n++; break; }
             if (n > 253) return -1;
             FseEntry e2 = lds_entry(sh.wt, s2);
+            lane0_guard();
             if (lane == 0) sh.weights[n] = (u8)e2.base_value;
             n++;
             s2 = e2.next_base + b.read(win, e2.nb_bits, lane);
@@ -337,6 +344,7 @@ __device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* s
     __syncthreads();
     // implied last weight
     __shared__ int lastw;
+    lane0_guard();
     if (lane == 0) {
         u32 sum = 0; bool ok = true;
         for (int i = 0; i < n; i++) { u32 w = sh.weights[i]; if (w > 12) ok = false; else if (w) sum += 1u << (w - 1); }
@@ -390,7 +398,7 @@ struct LaneBits {
 
 // decode `nstreams` (1 or 4) Huffman streams into lit[0..regen).  Whole wave; lanes 0..nstreams-1 work.
 __device__ inline bool huf_decode_streams(const ZstdShared& sh, const u8* p, u64 size, int nstreams, u8* lit, u64 regen,
-                                          const u8* rd_hi, int lane)
+                                          const u8* rd_hi, u64 deadline, int lane)
 {
     const u8* sp = p; u64 ssz = size; u8* out = lit; u64 cnt = regen;
     bool bad = false;
@@ -402,6 +410,7 @@ __device__ inline bool huf_decode_streams(const ZstdShared& sh, const u8* p, u64
         u64 seg = (regen + 3) / 4;
         if (seg * 3 > regen) return false;
         const u8* q = p + 6;
+        lane0_guard();
         if (lane == 0) { sp = q; ssz = s1; out = lit; cnt = seg; }
         else if (lane == 1) { sp = q + s1; ssz = s2; out = lit + seg; cnt = seg; }
         else if (lane == 2) { sp = q + s1 + s2; ssz = s3; out = lit + 2 * seg; cnt = seg; }
@@ -413,6 +422,7 @@ __device__ inline bool huf_decode_streams(const ZstdShared& sh, const u8* p, u64
             const int mb = (int)sh.huf_max_bits;
             LaneBits b; b.init(sp, ssz, rd_hi, highbit32(sp[ssz - 1]));
             for (u64 i = 0; i < cnt; i++) {
+                if ((i & 4095) == 4095 && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
                 u32 idx = b.peek(b.pos - mb, mb);              // zeros below bit 0
                 u32 e = sh.huf[idx];
                 out[i] = (u8)e;
@@ -427,6 +437,7 @@ __device__ inline bool huf_decode_streams(const ZstdShared& sh, const u8* p, u64
 // ---- one compressed block ------------------------------------------------------------------------
 
 struct ZFrameState {
+    Watchdog* wd;
     u64 rep0, rep1, rep2;
     bool seq_tables_valid;
     int al_ll, al_of, al_ml;
@@ -450,6 +461,7 @@ __device__ inline int read_seq_table(ZstdShared& sh, ByteWindow& win, int kind, 
         if (size < 1) return -1;
         u32 s = uld8(src);
         if ((int)s > max_sym) return -1;
+        lane0_guard();
         if (lane == 0) tab[0] = fse_rle_entry(kind, s);
         al = 0;
         return 1;
@@ -500,7 +512,7 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
             p += t; left -= (u64)t;
         } else if (!sh.huf_valid) return D_MALFORMED;
         __syncthreads();
-        if (!huf_decode_streams(sh, p, left, streams, lit_buf, regen, rd_hi, lane)) return D_MALFORMED;
+        if (!huf_decode_streams(sh, p, left, streams, lit_buf, regen, rd_hi, fs.wd->deadline, lane)) return D_MALFORMED;
         wave_mem_fence();
         lit_size = regen; used = hl + csize;
     }
@@ -534,6 +546,7 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         __syncthreads();
         {   // the FSE-described tables are built side by side, one lane each
             bool ok = true;
+            lane0_guard();
             if (lane == T_LL && (pending & (1 << T_LL))) ok = fse_build_lane(sh.ll, sh.ncount[T_LL], ns[T_LL], fs.al_ll, T_LL, sh.spread[T_LL], sh.nextc[T_LL]);
             if (lane == T_OF && (pending & (1 << T_OF))) ok = fse_build_lane(sh.of, sh.ncount[T_OF], ns[T_OF], fs.al_of, T_OF, sh.spread[T_OF], sh.nextc[T_OF]);
             if (lane == T_ML && (pending & (1 << T_ML))) ok = fse_build_lane(sh.ml, sh.ncount[T_ML], ns[T_ML], fs.al_ml, T_ML, sh.spread[T_ML], sh.nextc[T_ML]);
@@ -553,6 +566,7 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
             const int cnt = (int)(nseq - base < WAVE ? nseq - base : WAVE);
             u32 my_ll = 0, my_ml = 0; u64 my_off = 0;
             // ---- C1: parse up to 64 sequences wave-uniformly, sequence k lands in lane k's registers
+            if (fs.wd->expired()) return D_MALFORMED;
             for (int k = 0; k < cnt; k++) {
                 const u32 ofb = eof_.add_bits;
                 u64 of_val = (u64)eof_.base_value + b.read(win, (int)ofb, lane);
@@ -582,6 +596,7 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
             }
             // ---- execute the batch in order: literal run, then match, each by all 64 lanes
             for (int k = 0; k < cnt; k++) {
+                if (fs.wd->expired()) return D_MALFORMED;
                 const u64 ll = (u32)__builtin_amdgcn_readlane((int)my_ll, k);
                 const u64 ml = (u32)__builtin_amdgcn_readlane((int)my_ml, k);
                 const u64 off = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(my_off >> 32), k) << 32) |
@@ -621,13 +636,14 @@ __device__ inline void zstd_build_defaults(ZstdShared& sh, int lane)
     for (int i = lane; i < 29; i += WAVE) sh.ncount[T_OF][i] = Z_OF_DEF[i];
     for (int i = lane; i < 53; i += WAVE) sh.ncount[T_ML][i] = Z_ML_DEF[i];
     __syncthreads();
+    lane0_guard();
     if (lane == T_LL) fse_build_lane(sh.dll, sh.ncount[T_LL], 36, 6, T_LL, sh.spread[T_LL], sh.nextc[T_LL]);
     if (lane == T_OF) fse_build_lane(sh.dof, sh.ncount[T_OF], 29, 5, T_OF, sh.spread[T_OF], sh.nextc[T_OF]);
     if (lane == T_ML) fse_build_lane(sh.dml, sh.ncount[T_ML], 53, 6, T_ML, sh.spread[T_ML], sh.nextc[T_ML]);
     __syncthreads();
 }
 
-__device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u8* lit_buf, int lane)
+__device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u8* lit_buf, int lane)
 {
     DecodeOut r; r.rc = D_OK; r.produced = 0;
     const u8* ip = src; const u8* iend = src + src_size;
@@ -636,6 +652,7 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, const u8* src, u64 
     __syncthreads();
 
     while (ip < iend) {
+        if (wd.expired()) { r.rc = D_MALFORMED; break; }
         if (iend - ip < 4) { r.rc = D_MALFORMED; break; }
         const u32 magic = uld32(ip);
         if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
@@ -654,8 +671,8 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, const u8* src, u64 
         if (fhd & 0x08) { r.rc = D_MALFORMED; break; }
         if (!single) {
             if (iend - ip < 1) { r.rc = D_MALFORMED; break; }
-            const u32 wd = uld8(ip++);
-            if (10 + (wd >> 3) > 31) { r.rc = D_MALFORMED; break; }
+            const u32 wdesc = uld8(ip++);
+            if (10 + (wdesc >> 3) > 31) { r.rc = D_MALFORMED; break; }
         }
         const u32 dn = did_flag == 3 ? 4 : did_flag;
         if ((u64)(iend - ip) < dn) { r.rc = D_MALFORMED; break; }
@@ -671,12 +688,15 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, const u8* src, u64 
         ip += fn;
 
         ZFrameState fs;
+        fs.wd = &wd;
         fs.rep0 = 1; fs.rep1 = 4; fs.rep2 = 8; fs.seq_tables_valid = false; fs.al_ll = fs.al_of = fs.al_ml = 0;
+        lane0_guard();
         if (lane == 0) sh.huf_valid = 0;
         __syncthreads();
         u8* frame_lo = op;
         bool fail = false;
         for (;;) {
+            if (wd.expired()) { r.rc = D_MALFORMED; fail = true; break; }
             if (iend - ip < 3) { r.rc = D_MALFORMED; fail = true; break; }
             const u32 bh = uld8(ip) | (uld8(ip + 1) << 8) | (uld8(ip + 2) << 16);
             ip += 3;
@@ -708,6 +728,7 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, const u8* src, u64 
         if (cksum) {
             if (iend - ip < 4) { r.rc = D_MALFORMED; break; }
             u32 h = 0;
+            lane0_guard();
             if (lane == 0) h = (u32)xxh64_serial(frame_lo, (u64)(op - frame_lo), 0);
             if (uni(h) != uld32(ip)) { r.rc = D_MALFORMED; break; }
             ip += 4;
