@@ -136,6 +136,12 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
 
 /* ---- timing helper for benchmarks: elapsed device time of everything enqueued between the two
  * marks on `stream`, measured with HIP events on that stream ------------------------------- */
+/* per-kernel timing of decode batches: when enabled, every decode batch brackets each of its kernels
+ * with HIP events on the launch stream; zpk_codec_kernel_ms then returns the duration of kernel
+ * `which` (ZPK_K_*) in the most recent batch (synchronises on that batch). */
+enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2, ZPK_K_ZSTD = 3, ZPK_K_COUNT = 4 };
+int zpk_codec_set_profiling(zpk_codec* c, int enabled);
+int zpk_codec_kernel_ms(zpk_codec* c, int which, float* ms);
 int zpk_codec_timer_start(zpk_codec* c, void* stream);
 int zpk_codec_timer_stop(zpk_codec* c, void* stream, float* elapsed_ms);   /* synchronises the stop event */
 

@@ -16,6 +16,7 @@ ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
 
 METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
+K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD = 0, 1, 2, 3
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
 DECODE_DESC = np.dtype([("src_offset", "<u8"), ("comp_size", "<u8"), ("uncomp_size", "<u8"), ("expect_hash", "<u8"),
@@ -63,6 +64,8 @@ def lib():
         L.zpk_codec_compress_bound.restype = C.c_size_t
         L.zpk_codec_hash_batch_device.argtypes = [vp, u8p, vp, vp, u64, vp, vp]
         L.zpk_codec_hash_host.argtypes = [vp, u8p, u64, C.POINTER(u64)]
+        L.zpk_codec_set_profiling.argtypes = [vp, C.c_int]
+        L.zpk_codec_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
         L.zpk_codec_timer_start.argtypes = [vp, vp]
         L.zpk_codec_timer_stop.argtypes = [vp, vp, C.POINTER(C.c_float)]
         _lib = L
@@ -114,6 +117,14 @@ class Codec:
         st = C.c_void_p(stream) if stream else None
         self._chk(self.L.zpk_codec_hash_batch_device(self.h, src.data_ptr(), offsets_dev.data_ptr(), sizes_dev.data_ptr(),
                                                      n, hashes_dev.data_ptr(), st), "zpk_codec_hash_batch_device")
+
+    def set_profiling(self, on):
+        self._chk(self.L.zpk_codec_set_profiling(self.h, 1 if on else 0), "set_profiling")
+
+    def kernel_ms(self, which):
+        ms = C.c_float(0)
+        self._chk(self.L.zpk_codec_kernel_ms(self.h, which, C.byref(ms)), "kernel_ms")
+        return ms.value
 
     def timer_start(self, stream=None):
         self._chk(self.L.zpk_codec_timer_start(self.h, C.c_void_p(stream) if stream else None), "timer_start")

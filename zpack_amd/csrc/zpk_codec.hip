@@ -213,6 +213,8 @@ struct zpk_codec {
     void* d_desc = nullptr;      u64 desc_cap = 0;
     void* d_res = nullptr;       u64 res_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t kev[ZPK_K_COUNT][2] = {};
+    int profiling = 0;
     char err[256] = {0};
 };
 
@@ -275,6 +277,7 @@ void zpk_codec_destroy(zpk_codec* c)
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
     delete c;
 }
 
@@ -303,17 +306,26 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
         else if (trace == 2) { tev_name[tev_n] = name; (void)hipEventRecord(tev[tev_n++], st); } } while (0)
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 64, st));
     ZPK_TRACE_STEP("memset");
+#define ZPK_KEV(k, j) do { if (c->profiling) (void)hipEventRecord(c->kev[k][j], st); } while (0)
+    ZPK_KEV(ZPK_K_CLASSIFY, 0);
     hipLaunchKernelGGL(k_classify, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, desc, n, src_size, dst_size, res,
                        c->d_lists, stride, c->d_counters);
+    ZPK_KEV(ZPK_K_CLASSIFY, 1);
     ZPK_TRACE_STEP("k_classify");
     const u32 wgrid = (u32)((n + 3) / 4);          // one wave per list slot
+    ZPK_KEV(ZPK_K_STORED, 0);
     if (!(skip & 1)) hipLaunchKernelGGL(k_stored, dim3(wgrid), dim3(256), 0, st, src, desc, dst, res, c->d_lists + L_NONE * stride, c->d_counters);
+    ZPK_KEV(ZPK_K_STORED, 1);
     ZPK_TRACE_STEP("k_stored");
+    ZPK_KEV(ZPK_K_LZ4, 0);
     if (!(skip & 2)) hipLaunchKernelGGL(k_lz4_wave, dim3(wgrid), dim3(256), 0, st, src, read_lo, read_hi, desc, dst, res,
                        c->d_lists + L_LZ4 * stride, c->d_counters);
+    ZPK_KEV(ZPK_K_LZ4, 1);
     ZPK_TRACE_STEP("k_lz4_wave");
+    ZPK_KEV(ZPK_K_ZSTD, 0);
     if (!(skip & 4)) hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
                        c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit);
+    ZPK_KEV(ZPK_K_ZSTD, 1);
     ZPK_TRACE_STEP("k_zstd");
     if (trace == 2) {
         for (int spin = 0; spin < 100; spin++) {
@@ -430,6 +442,25 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
     hipLaunchKernelGGL(k_hash, dim3(1), dim3(64), 0, c->stream, c->d_src, m, m + 1, (u64)1, m + 2);
     HIPCHK(c, hipMemcpyAsync(hash, m + 2, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZPK_OK;
+}
+
+int zpk_codec_set_profiling(zpk_codec* c, int enabled)
+{
+    if (!c) return ZPK_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (enabled)
+        for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++)
+            if (!c->kev[i][j]) HIPCHK(c, hipEventCreate(&c->kev[i][j]));
+    c->profiling = enabled ? 1 : 0;
+    return ZPK_OK;
+}
+
+int zpk_codec_kernel_ms(zpk_codec* c, int which, float* ms)
+{
+    if (!c || !ms || which < 0 || which >= ZPK_K_COUNT || !c->kev[which][1]) return ZPK_E_INVALID;
+    HIPCHK(c, hipEventSynchronize(c->kev[which][1]));
+    HIPCHK(c, hipEventElapsedTime(ms, c->kev[which][0], c->kev[which][1]));
     return ZPK_OK;
 }
 
