@@ -141,6 +141,7 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
  * `which` (ZPK_K_*) in the most recent batch (synchronises on that batch). */
 enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2, ZPK_K_ZSTD = 3, ZPK_K_COUNT = 4 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
+int zpk_codec_debug_read(zpk_codec* c, void* host, uint64_t bytes);   /* developer aid: phase timing words */
 int zpk_codec_kernel_ms(zpk_codec* c, int which, float* ms);
 int zpk_codec_timer_start(zpk_codec* c, void* stream);
 int zpk_codec_timer_stop(zpk_codec* c, void* stream, float* elapsed_ms);   /* synchronises the stop event */

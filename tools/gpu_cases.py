@@ -67,11 +67,52 @@ def run_case(name):
             assert int(res[0]["status"]) == c["rc"], (c["label"], res[0])
             if c["rc"] == 0:
                 assert dg.xxh3(outs[0][:c["uncomp_size"]]) == c["plain_xxh3"], c["label"]
+    elif kind == "batch":
+        import torch
+        method, level, size, n, mix = [int(x) for x in arg.split(",")]
+        b = dg.Batch(n, size, method=method, level=level, seed=7, mix=mix)
+        desc, total = zpack_amd.decode_descs_from_batch(b)
+        dev = torch.device("cuda:0")
+        src = torch.from_numpy(b.archive).to(dev)
+        dst = torch.zeros(total, dtype=torch.uint8, device=dev)
+        ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+        dres = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        codec.set_profiling(True)
+        for it in range(3):
+            t = time.time()
+            codec.decode_batch_device(src, ddesc, n, dst, dres)
+            torch.cuda.synchronize()
+            print("    iter %d: %.3f ms wall, k_lz4 %.3f ms" % (it, (time.time() - t) * 1e3, codec.kernel_ms(zpack_amd.K_LZ4)), flush=True)
+        if os.environ.get("ZPK_DEBUG_TIMING"):
+            raw = codec.debug_read(n)
+            if True:
+                m = lambda k: float(np.median(raw[:, k]))
+                print("    wave kernel cycles (median/entry): parse %.0f lit %.0f dep %.0f rounds %.0f total %.0f | batches %.0f rounds %.0f coops %.0f redirects %.0f"
+                      % (m(0), m(1), m(2), m(3), m(6), np.median(raw[:, 4] >> 32), np.median(raw[:, 4] & 0xffffffff),
+                         np.median(raw[:, 5] >> 32), np.median(raw[:, 5] & 0xffffffff)), flush=True)
+            t = raw.astype(np.float64)
+            print("    phase cycles (median over entries): stage %.0f walk %.0f scan %.0f emit+lit %.0f match %.0f hash/flush %.0f | walk iters %.1f match iters %.0f"
+                  % tuple(np.median(t[:, k]) for k in (0, 1, 2, 3, 4, 7, 5, 6)), flush=True)
+            print("    max: ", t.max(axis=0)[:7], flush=True)
+        res = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)
+        out = dst.cpu().numpy()
+        nbad = int((res["status"] != 0).sum())
+        import collections
+        print("    bad status:", nbad, collections.Counter(res["detail"][res["status"] != 0].tolist()), res[res["status"] != 0][:3], flush=True)
+        assert nbad == 0
+        assert np.array_equal(res["hash"], b.hashes), "hash mismatch at %s" % np.nonzero(res["hash"] != b.hashes)[0][:5]
+        for i in range(0, n, max(1, n // 50)):
+            d = desc[i]
+            got = out[int(d["dst_offset"]):int(d["dst_offset"] + d["uncomp_size"])]
+            assert np.array_equal(got, b.plaintext(i)), "bytes differ entry %d" % i
     else:
         raise SystemExit("unknown case " + name)
     print("PASS", name, flush=True)
 
 
+CASES_LZ4 = ["ref:archive_lz4.zpk", "small:text/lz4_0", "small:runs/lz4_9", "small:random/lz4_0", "small:records/lz4_0", "status:lz4", "foreign:lz4f",
+             "batch:2,0,65536,64,0", "batch:2,0,65536,64,1", "batch:2,0,65536,64,2", "batch:2,0,65536,64,3", "batch:2,0,65536,2000,-1",
+             "batch:2,0,300000,64,-1", "batch:2,9,5000,300,-1"]
 CASES = ["ref:archive_none.zpk", "ref:archive_lz4.zpk", "ref:archive_zstd.zpk",
          "small:text/none", "small:text/lz4_0", "small:runs/lz4_9", "small:random/lz4_0",
          "small:text/zstd_3", "small:runs/zstd_19", "small:random/zstd_1", "small:records/zstd_1",
@@ -85,6 +126,8 @@ if __name__ == "__main__":
     t_all = time.time()
     os.environ.pop("ZPK_TRACE", None)
     cases = CASES
+    if "--lz4" in sys.argv:
+        cases = CASES_LZ4
     if "--bisect" in sys.argv:
         cases = []
         os.environ["ZPK_TRACE"] = "3"

@@ -66,6 +66,7 @@ def lib():
         L.zpk_codec_hash_host.argtypes = [vp, u8p, u64, C.POINTER(u64)]
         L.zpk_codec_set_profiling.argtypes = [vp, C.c_int]
         L.zpk_codec_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+        L.zpk_codec_debug_read.argtypes = [vp, vp, u64]
         L.zpk_codec_timer_start.argtypes = [vp, vp]
         L.zpk_codec_timer_stop.argtypes = [vp, vp, C.POINTER(C.c_float)]
         _lib = L
@@ -125,6 +126,11 @@ class Codec:
         ms = C.c_float(0)
         self._chk(self.L.zpk_codec_kernel_ms(self.h, which, C.byref(ms)), "kernel_ms")
         return ms.value
+
+    def debug_read(self, n):
+        a = np.zeros((n, 8), dtype=np.uint64)
+        self._chk(self.L.zpk_codec_debug_read(self.h, a.ctypes.data, a.nbytes), "debug_read")
+        return a
 
     def timer_start(self, stream=None):
         self._chk(self.L.zpk_codec_timer_start(self.h, C.c_void_p(stream) if stream else None), "timer_start")

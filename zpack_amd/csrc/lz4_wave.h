@@ -13,6 +13,7 @@
 #pragma once
 #include "zpk_device.h"
 #include "xxh3_device.h"
+#include "seq_exec.h"
 
 namespace zpk {
 
@@ -47,59 +48,184 @@ struct ByteWindow {
 
 struct DecodeOut { int rc; u64 produced; };
 
-// one LZ4 block: src [ip, iend) -> dst [op, ...), cap = oend; hist_lo = lowest output address a match may reach
-__device__ inline int lz4_block_wave(ByteWindow& win, Watchdog& wd, const u8* ip, const u8* iend, u8* dst_lo, u8*& op_io, u8* oend, int lane)
+// ---- LZ4 block decode: lane-parallel parse out of a per-wave LDS chunk, batched execution ----------
+//
+// The token chain is serial, and walking it wave-uniformly costs ~1000 cycles per sequence (a long
+// dependent scalar chain; measured).  Instead the block is taken in chunks of 64 segments x LZ4W_SEG
+// bytes staged in LDS: every lane walks its own segment from a guessed entry, then re-walks from its
+// predecessor's exit until no entry changes (LZ4 chains re-synchronise within a few tokens; lane 0's
+// entry is the true chain position, so the fixed point is the true chain).  A wave prefix sum numbers
+// the chunk's sequences, one more walk writes each sequence's token position into a u16 record array,
+// and the chunk is then executed 64 consecutive sequences at a time: lane k re-reads token k's fields
+// from LDS and seq_exec_batch() (seq_exec.h) does the copies in HBM/L2 with in-register dependency
+// masks.  LDS per wave: 5.4 KiB chunk + 3.6 KiB records.
+#define LZ4W_SEG 84u                            // 21 dwords: odd, so 64 lanes spread over all LDS banks
+#define LZ4W_CHUNK (64u * LZ4W_SEG)             // 5376
+#define LZ4W_SLACK 64u
+#define LZ4W_MAXREC (LZ4W_CHUNK / 3u + 64u)
+
+struct alignas(16) Lz4WaveShared {
+    u8  stage[LZ4W_CHUNK + LZ4W_SLACK];
+    u16 rec[LZ4W_MAXREC];
+};
+
+// byte `pos` of the block: from the staged chunk when it is there, else from memory (only a sequence
+// whose literal run crosses the end of the chunk gets there)
+struct Lz4Bytes {
+    const u8* S;          // staged chunk (LDS)
+    const u8* g;          // block base in memory
+    u32 cbase, cend;      // the chunk holds block bytes [cbase, cend)
+    __device__ __forceinline__ u32 at(u32 pos) const { return pos < cend ? (u32)S[pos - cbase] : (u32)g[pos]; }
+};
+
+// flags: 1 = malformed, 2 = this was the block's last (literal-only) sequence
+struct Lz4Tok { u32 next, lit_pos, lit, ml, off, flags; };
+
+// full decode of the sequence whose token is at block position p (p < C)
+__device__ __forceinline__ Lz4Tok lz4_token_at(const Lz4Bytes& B, u32 p, u32 C, bool want_offset)
+{
+    Lz4Tok t; t.flags = 0; t.ml = 0; t.off = 1;
+    const u32 tok = B.at(p);
+    u32 q = p + 1, lit = tok >> 4;
+    if (lit == 15) {
+        u32 b;
+        do {
+            if (q >= C) { t.flags = 1; t.next = C; t.lit = 0; t.lit_pos = q; return t; }
+            b = B.at(q++); lit += b;
+        } while (b == 255 && lit < 0x7F000000u);
+        if (b == 255) { t.flags = 1; t.next = C; t.lit = 0; t.lit_pos = q; return t; }
+    }
+    t.lit_pos = q; t.lit = lit;
+    if (lit > C - q) { t.flags = 1; t.next = C; return t; }
+    q += lit;
+    if (q == C) { t.flags = 2; t.next = C; return t; }
+    if (C - q < 2) { t.flags = 1; t.next = C; return t; }
+    if (want_offset) t.off = B.at(q) | (B.at(q + 1) << 8);
+    q += 2;
+    u32 ml = tok & 15;
+    if (ml == 15) {
+        u32 b;
+        do {
+            if (q >= C) { t.flags = 1; t.next = C; return t; }
+            b = B.at(q++); ml += b;
+        } while (b == 255 && ml < 0x7F000000u);
+        if (b == 255) { t.flags = 1; t.next = C; return t; }
+    }
+    t.ml = ml + 4;
+    t.next = q;
+    return t;
+}
+
+// walk from `entry` while the token lies before seg_end; counts sequences, ORs flags
+struct Lz4Walk { u32 exit, nseq, flags; };
+__device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, u32 entry, u32 seg_end, u32 C)
+{
+    Lz4Walk w; w.nseq = 0; w.flags = 0;
+    u32 p = entry;
+    while (p < seg_end) {
+        const Lz4Tok t = lz4_token_at(B, p, C, false);
+        w.nseq++;
+        w.flags |= t.flags;
+        p = t.next;
+        if (t.flags) break;
+    }
+    w.exit = p;
+    return w;
+}
+
+// one LZ4 block: src [ip, ip+C) -> dst [op, ...), cap = oend; dst_lo = lowest output address a match may reach
+__device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* ip, u32 C, const u8* rd_hi,
+                                     u8* dst_lo, u8*& op_io, u8* oend, int lane)
 {
     u8* op = op_io;
-    if (ip >= iend) return D_MALFORMED;
-    for (;;) {
-        if (ip >= iend || wd.expired()) return D_MALFORMED;
-        u32 tok = win.byte(ip++, lane);
-        u64 lit = tok >> 4;
-        if (lit == 15) {
-            u32 b;
-            do {
-                if (ip >= iend) return D_MALFORMED;
-                b = win.byte(ip++, lane);
-                lit += b;
-            } while (b == 255);
-        }
-        if (lit > (u64)(iend - ip)) return D_MALFORMED;
-        if (lit > (u64)(oend - op)) { op_io = op; return D_DST_FULL; }
-        for (u64 i = lane; i < lit; i += WAVE) op[i] = ip[i];
-        ip += lit; op += lit;
-        if (ip == iend) break;
-        if (iend - ip < 2) return D_MALFORMED;
-        u32 off = win.byte(ip, lane) | (win.byte(ip + 1, lane) << 8);
-        ip += 2;
-        if (off == 0 || (u64)off > (u64)(op - dst_lo)) return D_MALFORMED;
-        u64 ml = tok & 15;
-        if (ml == 15) {
-            u32 b;
-            do {
-                if (ip >= iend) return D_MALFORMED;
-                b = win.byte(ip++, lane);
-                ml += b;
-            } while (b == 255);
-        }
-        ml += 4;
-        if (ml > (u64)(oend - op)) { op_io = op; return D_DST_FULL; }
-        wave_mem_fence();                                  // literals above are match sources
-        const u8* m = op - off;
-        if ((u64)off >= ml) {
-            for (u64 i = lane; i < ml; i += WAVE) op[i] = m[i];
-        } else {
-            for (u64 i = lane; i < ml; i += WAVE) op[i] = m[(u32)i % off];
-        }
+    if (C == 0) return D_MALFORMED;
+    u32 cpos = 0;                                   // block position of the next token of the true chain
+    bool finished = false;
+    while (!finished) {
+        if (wd.expired()) return D_MALFORMED;
+        const u64 tp0 = SEQ_T();
+        if (cpos >= C) return D_MALFORMED;          // the chain ran off the block without a final literal run
+        // ---- stage [cpos, cpos + nst) ----
+        const u32 nst = C - cpos < LZ4W_CHUNK + LZ4W_SLACK ? C - cpos : LZ4W_CHUNK + LZ4W_SLACK;
+        const u32 tok_end = C - cpos < LZ4W_CHUNK ? C : cpos + LZ4W_CHUNK;      // tokens of this chunk lie before tok_end
         wave_mem_fence();
-        op += ml;
+        for (u32 i = (u32)lane * 16; i < nst; i += WAVE * 16) {
+            const u8* g = ip + cpos + i;
+            if (i + 16 <= nst && g + 16 <= rd_hi) { u128 v = ld128(g); __builtin_memcpy(sh.stage + i, &v, 16); }
+            else for (u32 k = i; k < nst && k < i + 16; k++) sh.stage[k] = ip[cpos + k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        Lz4Bytes B; B.S = sh.stage; B.g = ip; B.cbase = cpos; B.cend = cpos + nst;
+        // ---- walks to the fixed point ----
+        const u32 my_start = cpos + (u32)lane * LZ4W_SEG;
+        const u32 my_end = my_start + LZ4W_SEG < tok_end ? my_start + LZ4W_SEG : tok_end;
+        const bool active = my_start < tok_end;
+        u32 my_entry = my_start;
+        Lz4Walk w; w.exit = my_start; w.nseq = 0; w.flags = 0;
+        if (active) w = lz4_walk(B, my_entry, my_end, C);
+        for (int iter = 0; iter < 66; iter++) {
+            u32 e = (u32)__shfl_up((int)w.exit, 1, 64);
+            if (lane == 0) e = cpos;
+            const bool changed = active && e != my_entry;
+            if (__ballot(changed) == 0) break;
+            if (changed) { my_entry = e; w = lz4_walk(B, my_entry, my_end, C); }
+        }
+        // inactive lanes forward the chain position
+        if (!active) { w.exit = (u32)__shfl((int)w.exit, 63, 64); }
+        const u64 lastmask = __ballot(active);
+        const int last_lane = 63 - __clzll((long long)lastmask);
+        const u32 chain_exit = (u32)__builtin_amdgcn_readlane((int)w.exit, last_lane);
+        const u32 fl = (u32)__ballot(active && (w.flags & 1)) != 0 || (__ballot(active && (w.flags & 1)) >> 32) != 0 ? 1u : 0u;
+        if (fl) return D_MALFORMED;
+        if (__ballot(active && (w.flags & 2)) != 0) finished = true;          // the block's last sequence is in this chunk
+        // ---- sequence numbers + token records ----
+        u32 x = active ? w.nseq : 0u;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
+        const u32 nseq = (u32)__builtin_amdgcn_readlane((int)x, 63);
+        if (nseq > LZ4W_MAXREC) return D_MALFORMED;                           // cannot happen: >= 3 bytes per sequence
+        if (active) {
+            u32 k = x - w.nseq, p = my_entry;
+            while (p < my_end) {
+                sh.rec[k++] = (u16)(p - cpos);
+                const Lz4Tok t = lz4_token_at(B, p, C, false);
+                p = t.next;
+                if (t.flags) break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        stt.t_parse += SEQ_T() - tp0;
+        // ---- execute, 64 consecutive sequences at a time ----
+        for (u32 b0 = 0; b0 < nseq; b0 += WAVE) {
+            const int cnt = (int)(nseq - b0 < WAVE ? nseq - b0 : WAVE);
+            const u64 tq0 = SEQ_T();
+            SeqBatch q; q.lit = ip; q.ll = 0; q.ml = 0; q.off = 1;
+            bool bad = false;
+            if (lane < cnt) {
+                const u32 p = cpos + sh.rec[b0 + (u32)lane];
+                const Lz4Tok t = lz4_token_at(B, p, C, true);
+                q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
+                bad = (t.flags & 1) || (t.ml && t.off == 0) || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
+            }
+            stt.t_parse += SEQ_T() - tq0;
+            if (__ballot(bad) != 0) {
+                // oversize lengths mean the output slot is too small (or the input is malformed): let the sums decide
+                if (__ballot(lane < cnt && (q.ll > (u64)(oend - op) || q.ml > (u64)(oend - op))) != 0) { op_io = op; return D_DST_FULL; }
+                return D_MALFORMED;
+            }
+            const int rc = seq_exec_batch(q, cnt, op, oend, dst_lo, -1, lane, stt);
+            if (rc != D_OK) { op_io = op; return rc; }
+        }
+        if (!finished && chain_exit <= cpos) return D_MALFORMED;               // no progress: cannot happen
+        cpos = chain_exit;
     }
+    if (cpos != C) return D_MALFORMED;
     op_io = op;
     return D_OK;
 }
 
 // whole frame.  src_lo/src_hi bound what may be READ (the archive image); all values uniform.
-__device__ inline DecodeOut lz4f_decode_wave(Watchdog& wd, const u8* src, u64 src_size, const u8* src_lo, const u8* src_hi,
+__device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* src, u64 src_size, const u8* src_lo, const u8* src_hi,
                                              u8* dst, u64 dst_cap, int lane)
 {
     DecodeOut r; r.rc = D_OK; r.produced = 0;
@@ -182,7 +308,7 @@ __device__ inline DecodeOut lz4f_decode_wave(Watchdog& wd, const u8* src, u64 sr
             u8* bend = oend;
             bool limited = false;
             if ((u64)(oend - op) > bmax) { bend = op + bmax; limited = true; }
-            int rc = lz4_block_wave(win, wd, ip, ip + bsz, hist_lo, op, bend, lane);
+            int rc = lz4_block_wave(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane);
             if (rc == D_DST_FULL) {
                 if (limited) { r.rc = D_MALFORMED; return r; }
                 r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r;

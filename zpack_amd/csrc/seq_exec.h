@@ -1,0 +1,227 @@
+// seq_exec.h — execute a batch of up to 64 LZ sequences with one wave, lane-parallel.
+//
+// Shared by the LZ4 (lz4_wave.h) and Zstandard (zstd_wg.h) decoders: both parse their token /
+// FSE streams wave-uniformly into lane registers — lane k holds sequence k = (literal source, literal
+// length, match length, offset) — and hand the batch to seq_exec_batch().
+//
+//   1. wave prefix sum of (literal length + match length): every sequence's output position
+//      (the "wavefront prefix-sum for output offsets")
+//   2. literal runs are copied by their own lanes (16 B per lane per instruction, exact tails); runs
+//      longer than 64 B are copied by the whole wave, 1 KiB per instruction.  Literals depend on nothing.
+//   3. matches: a match may read bytes written by earlier matches OF THE SAME BATCH (everything older is
+//      already in memory).  Each lane builds the 64-bit mask of batch lanes whose match output its
+//      source range touches — sequences are sorted by output position, so this is one uniform sweep with
+//      v_readlane, no memory — and, where its whole source lies inside ONE earlier match, it re-points
+//      the source at THAT match's source (window[x] == window[x - offset] holds for every byte of a
+//      match), which collapses copy-of-a-copy chains without waiting for them.
+//   4. rounds: all lanes whose dependencies are done copy at once (short, non-overlapping matches by
+//      their own lane; long or self-overlapping ones by the whole wave, period handled with a modulo);
+//      the done mask is a ballot.  The lowest unfinished sequence is always ready, so the loop ends.
+//
+// One round costs about one HBM/L2 round trip for up to 64 sequences, where the serial decoder paid one
+// or two round trips per sequence.
+#pragma once
+#include "zpk_device.h"
+
+namespace zpk {
+
+// copy exactly n (0..16) bytes, global -> global, any alignment, never touching byte n or beyond
+__device__ __forceinline__ void gcopy_upto16(u8* d, const u8* s, u32 n)
+{
+    if (n >= 16) { st128(d, ld128(s)); return; }
+    if (n & 8) { st64(d, ld64(s)); d += 8; s += 8; }
+    if (n & 4) { st32(d, ld32(s)); d += 4; s += 4; }
+    if (n & 2) { u16 v = ld16(s); __builtin_memcpy(d, &v, 2); d += 2; s += 2; }
+    if (n & 1) *d = *s;
+}
+
+// the same in two halves, so that several chunks can be in flight before the first store
+__device__ __forceinline__ u128 gload_upto16(const u8* s, u32 n)
+{
+    if (n >= 16) return ld128(s);
+    u64 lo = 0, t = 0;
+    u32 pos = 0, sh = 0;
+    if (n & 8) { lo = ld64(s); pos = 8; }
+    const u8* p = s + pos;
+    if (n & 4) { t = (u64)ld32(p); sh = 32; p += 4; }
+    if (n & 2) { t |= (u64)ld16(p) << sh; sh += 16; p += 2; }
+    if (n & 1) { t |= (u64)(*p) << sh; }
+    u128 v;
+    if (pos) { v.lo = lo; v.hi = t; } else { v.lo = t; v.hi = 0; }
+    return v;
+}
+__device__ __forceinline__ void gstore_upto16(u8* d, u128 v, u32 n)
+{
+    if (n >= 16) { st128(d, v); return; }
+    u64 t = v.lo;
+    if (n & 8) { st64(d, v.lo); d += 8; t = v.hi; }
+    if (n & 4) { st32(d, (u32)t); d += 4; t >>= 32; }
+    if (n & 2) { u16 h = (u16)t; __builtin_memcpy(d, &h, 2); d += 2; t >>= 16; }
+    if (n & 1) *d = (u8)t;
+}
+// up to 64 bytes: every load is issued before the first store (one memory round trip)
+__device__ __forceinline__ void gcopy_upto64(u8* d, const u8* s, u32 n)
+{
+    u128 v0 = {0, 0}, v1 = {0, 0}, v2 = {0, 0}, v3 = {0, 0};
+    if (n > 0) v0 = gload_upto16(s, n);
+    if (n > 16) v1 = gload_upto16(s + 16, n - 16);
+    if (n > 32) v2 = gload_upto16(s + 32, n - 32);
+    if (n > 48) v3 = gload_upto16(s + 48, n - 48);
+    if (n > 0) gstore_upto16(d, v0, n);
+    if (n > 16) gstore_upto16(d + 16, v1, n - 16);
+    if (n > 32) gstore_upto16(d + 32, v2, n - 32);
+    if (n > 48) gstore_upto16(d + 48, v3, n - 48);
+}
+
+__device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
+{
+    return (const u8*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)p >> 32), k) << 32) |
+                       (u32)__builtin_amdgcn_readlane((int)(u32)(u64)p, k));
+}
+
+// developer aid: cycle accounting of the executor (kept in registers; written out only when asked)
+struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; };
+#define SEQ_T() __builtin_amdgcn_s_memtime()
+
+struct SeqBatch {
+    const u8* lit;     // literal source of this lane's sequence (ignored when lit_rle)
+    u32 ll, ml;        // literal length, match length (0 = no match)
+    u32 off;           // match offset (>= 1 when ml != 0)
+};
+
+// Execute `cnt` sequences (lane k < cnt holds sequence k).  op = output cursor (uniform, advanced),
+// oend = end of the output slot, dst_lo = lowest address a match may read.  lit_rle >= 0: every literal
+// byte equals that value (Zstandard RLE literals).  Returns D_OK / D_MALFORMED / D_DST_FULL.
+__device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& op, u8* oend, const u8* dst_lo, int lit_rle, int lane,
+                                              SeqStats& stt)
+{
+    u64 t0 = SEQ_T();
+    stt.batches++;
+    const bool act = lane < cnt;
+    const u32 ll = act ? q.ll : 0u, ml = act ? q.ml : 0u;
+    // ---- 1. output positions ----
+    u32 x = ll + ml;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
+    const u64 total = (u32)__builtin_amdgcn_readlane((int)x, 63);
+    if (total > (u64)(oend - op)) return D_DST_FULL;
+    u8* const o = op + (x - (ll + ml));          // literal start of this lane's sequence
+    u8* const ms = o + ll;                        // match start
+    const bool has_match = act && ml != 0;
+    if (__ballot(has_match && (q.off == 0 || (u64)q.off > (u64)(ms - dst_lo))) != 0) return D_MALFORMED;
+
+    // ---- 2. literals ----
+    if (lit_rle >= 0) {
+        if (__ballot(ll > 64) == 0) { for (u32 c = 0; c < ll; c++) o[c] = (u8)lit_rle; }
+        else {
+            for (int k = 0; k < cnt; k++) {
+                const u32 n = (u32)__builtin_amdgcn_readlane((int)ll, k);
+                u8* p = (u8*)readlane_ptr(o, k);
+                for (u32 c = lane; c < n; c += WAVE) p[c] = (u8)lit_rle;
+            }
+        }
+    } else {
+        const bool long_lit = ll > 64;
+        if (!long_lit) gcopy_upto64(o, q.lit, ll);
+        u64 lm = __ballot(long_lit);
+        while (lm) {                              // long runs: whole wave, 16 B per lane
+            const int k = __ffsll((long long)lm) - 1;
+            lm &= lm - 1;
+            const u32 n = (u32)__builtin_amdgcn_readlane((int)ll, k);
+            u8* p = (u8*)readlane_ptr(o, k);
+            const u8* s = readlane_ptr(q.lit, k);
+            for (u32 c = (u32)lane * 16; c < n; c += WAVE * 16) gcopy_upto16(p + c, s + c, n - c);
+        }
+    }
+    wave_mem_fence();
+    u64 pending = __ballot(has_match);
+    { u64 t1 = SEQ_T(); stt.t_lit += t1 - t0; t0 = t1; }
+    if (pending == 0) { op += total; return D_OK; }
+
+    // ---- 3. in-batch dependencies (positions relative to op fit 32 bits) ----
+    const u32 r_ms = (u32)(ms - op), r_me = r_ms + ml;           // this lane's match output [r_ms, r_me)
+    i64 src = (i64)r_ms - (i64)q.off;                             // source start, relative to op (negative = older data)
+    u32 need_len = ml < q.off ? ml : q.off;                       // bytes not produced by the match itself
+    u64 need = 0;
+    #pragma unroll 1
+    for (int round = 0; round < 4; round++) {
+        // which earlier matches of the batch does [src, src+need_len) touch?  Output ranges are sorted by
+        // lane, so two binary searches over the wave (ds_bpermute, no memory) give the lane interval.
+        need = 0;
+        int inside = -1;                                           // lane whose match range contains the whole source
+        const i64 send = src + (i64)need_len;
+        const bool reads_batch = has_match && send > 0;
+        if (__ballot(reads_batch) == 0) break;                     // nobody reads batch output
+        int klo = 0, khi = 0;                                      // klo = first lane with r_me > src; khi = first lane with r_ms >= send
+        #pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const u32 a = (u32)__shfl((int)r_me, klo + step - 1, 64);
+            const u32 b = (u32)__shfl((int)r_ms, khi + step - 1, 64);
+            if ((i64)a <= src) klo += step;
+            if ((i64)b < send) khi += step;
+        }
+        if (reads_batch && klo < khi) {
+            if (khi > lane) khi = lane;
+            const u64 span = (khi >= 64 ? ~0ull : ((1ull << khi) - 1)) & ~((1ull << klo) - 1);
+            need = span & pending;                                 // only lanes that actually have a match
+            if (need && (need & (need - 1)) == 0) inside = __ffsll((long long)need) - 1;   // exactly one candidate
+        }
+        {   // cross-lane reads stay outside divergent control flow
+            const int probe = inside < 0 ? lane : inside;
+            const u32 kms = (u32)__shfl((int)r_ms, probe, 64), kme = (u32)__shfl((int)r_me, probe, 64);
+            if (inside >= 0 && !((i64)kms <= src && send <= (i64)kme)) inside = -1;
+        }
+        // re-point sources that sit entirely inside one earlier match at that match's own source; the
+        // last sweep never redirects, so `need` always describes the final source
+        const u32 koff = (u32)__shfl((int)q.off, inside < 0 ? lane : inside, 64);
+        if (round == 3 || __ballot(inside >= 0) == 0) break;
+        if (inside >= 0) src -= (i64)koff;
+        stt.redirects += (u32)__popcll(__ballot(inside >= 0));
+    }
+    { u64 t1 = SEQ_T(); stt.t_dep += t1 - t0; t0 = t1; }
+
+    // ---- 4. rounds ----
+    const u8* const srcp = op + src;                               // (possibly re-pointed) source of the first need_len bytes
+    const bool self_overlap = ml > need_len;                       // offset < length: the match feeds itself
+    const bool coop = has_match && (ml > 64 || self_overlap);
+    u64 done = ~__ballot(has_match);                               // lanes without a match count as done
+    u32 guard = 0;
+    while (pending) {
+        const bool ready = has_match && ((pending >> lane) & 1) && (need & ~done) == 0;
+        const u64 rmask = __ballot(ready);
+        if (rmask == 0 || ++guard > 70) return D_MALFORMED;        // cannot happen: the lowest pending lane is always ready
+        stt.rounds++;
+        if (ready && !coop) gcopy_upto64(ms, srcp, ml);            // whole source final and not produced by this match
+        u64 cm = __ballot(ready && coop);
+        stt.coops += (u32)__popcll(cm);
+        while (cm) {
+            const int k = __ffsll((long long)cm) - 1;
+            cm &= cm - 1;
+            const u32 n = (u32)__builtin_amdgcn_readlane((int)ml, k);
+            const u32 koff = (u32)__builtin_amdgcn_readlane((int)q.off, k);
+            u8* p = (u8*)readlane_ptr(ms, k);
+            const u8* m = readlane_ptr(srcp, k);                   // first period (or whole source) of match k
+            if (koff >= n) { for (u32 c = (u32)lane * 16; c < n; c += WAVE * 16) gcopy_upto16(p + c, m + c, n - c); }
+            else if (koff >= 16) {
+                // period >= 16: slab by slab, so that no lane reads what the same instruction writes
+                for (u32 c = (u32)lane * 16; c < koff; c += WAVE * 16) gcopy_upto16(p + c, m + c, koff - c);
+                wave_mem_fence();
+                for (u32 base = koff; base < n; base += koff) {
+                    const u32 slab = n - base < koff ? n - base : koff;
+                    for (u32 c = (u32)lane * 16; c < slab; c += WAVE * 16) gcopy_upto16(p + base + c, p + base - koff + c, slab - c);
+                    wave_mem_fence();
+                }
+            } else {
+                for (u32 c = lane; c < n; c += WAVE) p[c] = m[c % koff];
+            }
+        }
+        wave_mem_fence();
+        done |= rmask;
+        pending &= ~rmask;
+    }
+    { u64 t1 = SEQ_T(); stt.t_rounds += t1 - t0; }
+    op += total;
+    return D_OK;
+}
+
+}  // namespace zpk

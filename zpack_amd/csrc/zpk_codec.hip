@@ -23,8 +23,8 @@
 
 using namespace zpk;
 
-// counters layout (u32): [0..3] count per method list, [4..7] dequeue head per list
-enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4 };
+// counters layout (u32): [0..3] count per work list, [4..7] dequeue head per list
+enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4, N_LISTS = 3 };
 
 // ------------------------------------------------------------------------------------ kernels
 
@@ -141,12 +141,13 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
     }
 }
 
-__global__ __launch_bounds__(256) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
+__global__ __launch_bounds__(64) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
-                                                  const u32* __restrict__ counters)
+                                                  const u32* __restrict__ counters, u64* __restrict__ dbg)
 {
     const int lane = lane_id();
+    __shared__ Lz4WaveShared shw;
     u32 idx;
     if (my_slot(counters, L_LZ4, idx)) {
         const u32 e = uni(list[idx]);
@@ -154,7 +155,14 @@ __global__ __launch_bounds__(256) void k_lz4_wave(const u8* __restrict__ src, co
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
         Watchdog wd; wd.arm();
-        DecodeOut o = lz4f_decode_wave(wd, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
+        SeqStats stt = {};
+        const u64 t_all = SEQ_T();
+        DecodeOut o = lz4f_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
+        if (dbg && lane == 0) {
+            u64* g = dbg + (u64)e * 8;
+            g[0] = stt.t_parse; g[1] = stt.t_lit; g[2] = stt.t_dep; g[3] = stt.t_rounds;
+            g[4] = ((u64)stt.batches << 32) | stt.rounds; g[5] = ((u64)stt.coops << 32) | stt.redirects; g[6] = SEQ_T() - t_all;
+        }
         // lib/zpack_read.c:421-450
         int status = R_OK;
         if (o.rc == D_MALFORMED) status = R_DECOMPRESS_FAILED;
@@ -212,6 +220,7 @@ struct zpk_codec {
     u8*  d_dst = nullptr;        u64 dst_cap = 0;
     void* d_desc = nullptr;      u64 desc_cap = 0;
     void* d_res = nullptr;       u64 res_cap = 0;
+    u64* d_dbg = nullptr;        u64 dbg_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t kev[ZPK_K_COUNT][2] = {};
     int profiling = 0;
@@ -291,8 +300,10 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     if (n == 0) return ZPK_OK;
     if (n > 0xFFFFFFF0ull) return ZPK_E_INVALID;
     int rc;
-    if ((rc = grow(c, (void**)&c->d_lists, &c->list_cap, 3 * n * sizeof(u32)))) return rc;
-    const u64 stride = c->list_cap / (3 * sizeof(u32));
+    if ((rc = grow(c, (void**)&c->d_lists, &c->list_cap, N_LISTS * n * sizeof(u32)))) return rc;
+    const u64 stride = c->list_cap / (N_LISTS * sizeof(u32));
+    static const int want_dbg = getenv("ZPK_DEBUG_TIMING") ? atoi(getenv("ZPK_DEBUG_TIMING")) : 0;
+    if (want_dbg) { if ((rc = grow(c, (void**)&c->d_dbg, &c->dbg_cap, n * 64))) return rc; }
     const u32 zstd_grid = (u32)(n < ZSTD_GRID_MAX ? n : ZSTD_GRID_MAX);
     if ((rc = grow(c, (void**)&c->d_lit, &c->lit_cap, (u64)ZSTD_GRID_MAX * ZSTD_LIT_SCRATCH))) return rc;
     // debugging aids: ZPK_TRACE=1 synchronises and reports after every launch, ZPK_SKIP=<bitmask> leaves
@@ -318,8 +329,8 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_KEV(ZPK_K_STORED, 1);
     ZPK_TRACE_STEP("k_stored");
     ZPK_KEV(ZPK_K_LZ4, 0);
-    if (!(skip & 2)) hipLaunchKernelGGL(k_lz4_wave, dim3(wgrid), dim3(256), 0, st, src, read_lo, read_hi, desc, dst, res,
-                       c->d_lists + L_LZ4 * stride, c->d_counters);
+    if (!(skip & 2)) hipLaunchKernelGGL(k_lz4_wave, dim3((u32)n), dim3(64), 0, st, src, read_lo, read_hi, desc, dst, res,
+                       c->d_lists + L_LZ4 * stride, c->d_counters, c->d_dbg);
     ZPK_KEV(ZPK_K_LZ4, 1);
     ZPK_TRACE_STEP("k_lz4_wave");
     ZPK_KEV(ZPK_K_ZSTD, 0);
@@ -442,6 +453,15 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
     hipLaunchKernelGGL(k_hash, dim3(1), dim3(64), 0, c->stream, c->d_src, m, m + 1, (u64)1, m + 2);
     HIPCHK(c, hipMemcpyAsync(hash, m + 2, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZPK_OK;
+}
+
+// debugging: copy the per-entry phase timing words (8 x u64 per entry; needs ZPK_DEBUG_TIMING=1) to the host
+int zpk_codec_debug_read(zpk_codec* c, void* host, uint64_t bytes)
+{
+    if (!c || !c->d_dbg || bytes > c->dbg_cap) return ZPK_E_INVALID;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(host, c->d_dbg, bytes, hipMemcpyDeviceToHost));
     return ZPK_OK;
 }
 
