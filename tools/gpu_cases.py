@@ -85,8 +85,11 @@ def run_case(name):
             print("    iter %d: %.3f ms wall, k_lz4 %.3f ms" % (it, (time.time() - t) * 1e3, codec.kernel_ms(zpack_amd.K_LZ4)), flush=True)
         if os.environ.get("ZPK_DEBUG_TIMING"):
             raw = codec.debug_read(n)
-            if True:
-                m = lambda k: float(np.median(raw[:, k]))
+            m = lambda k: float(np.median(raw[:, k]))
+            if os.environ.get("ZPK_DEBUG_TIMING") == "2":
+                print("    parse split (median cycles/entry): stage %.0f walk1 %.0f fix %.0f emit+scan %.0f token-fetch %.0f | fix iters %.0f chunks %.0f"
+                      % (m(0), m(1), m(2), m(3), m(4), np.median(raw[:, 7] >> 32), np.median(raw[:, 7] & 0xffffffff)), flush=True)
+            else:
                 print("    wave kernel cycles (median/entry): parse %.0f lit %.0f dep %.0f rounds %.0f total %.0f | batches %.0f rounds %.0f coops %.0f redirects %.0f"
                       % (m(0), m(1), m(2), m(3), m(6), np.median(raw[:, 4] >> 32), np.median(raw[:, 4] & 0xffffffff),
                          np.median(raw[:, 5] >> 32), np.median(raw[:, 5] & 0xffffffff)), flush=True)

@@ -29,10 +29,10 @@ struct ByteWindow {
         base = (const u8*)((u64)p & ~(u64)3);
         const u8* a = base + 4 * lane;
         u32 v = 0;
-        if (a >= lo && a + 4 <= hi) v = *(const u32*)a;
+        if (a >= lo && a + 4 <= hi) v = ld32(a);
         else {
             #pragma unroll
-            for (int i = 0; i < 4; i++) if (a + i >= lo && a + i < hi) v |= (u32)a[i] << (8 * i);
+            for (int i = 0; i < 4; i++) if (a + i >= lo && a + i < hi) v |= (u32)ld8(a + i) << (8 * i);
         }
         w = v;
     }
@@ -72,10 +72,19 @@ struct alignas(16) Lz4WaveShared {
 // byte `pos` of the block: from the staged chunk when it is there, else from memory (only a sequence
 // whose literal run crosses the end of the chunk gets there)
 struct Lz4Bytes {
-    const u8* S;          // staged chunk (LDS)
+    lds_cp8 S;            // staged chunk (LDS, typed: ds_read, never a flat load)
     const u8* g;          // block base in memory
     u32 cbase, cend;      // the chunk holds block bytes [cbase, cend)
-    __device__ __forceinline__ u32 at(u32 pos) const { return pos < cend ? (u32)S[pos - cbase] : (u32)g[pos]; }
+    __device__ __forceinline__ u32 at(u32 pos) const
+    {
+        if (pos < cend) return lds_ld8(S + (pos - cbase));
+        return (u32)ld8(g + pos);
+    }
+    __device__ __forceinline__ u32 at16(u32 pos) const
+    {
+        if (pos + 1 < cend) return lds_ld16(S + (pos - cbase));
+        return at(pos) | (at(pos + 1) << 8);
+    }
 };
 
 // flags: 1 = malformed, 2 = this was the block's last (literal-only) sequence
@@ -100,7 +109,7 @@ __device__ __forceinline__ Lz4Tok lz4_token_at(const Lz4Bytes& B, u32 p, u32 C, 
     q += lit;
     if (q == C) { t.flags = 2; t.next = C; return t; }
     if (C - q < 2) { t.flags = 1; t.next = C; return t; }
-    if (want_offset) t.off = B.at(q) | (B.at(q + 1) << 8);
+    if (want_offset) t.off = B.at16(q);
     q += 2;
     u32 ml = tok & 15;
     if (ml == 15) {
@@ -116,20 +125,50 @@ __device__ __forceinline__ Lz4Tok lz4_token_at(const Lz4Bytes& B, u32 p, u32 C, 
     return t;
 }
 
-// walk from `entry` while the token lies before seg_end; counts sequences, ORs flags
-struct Lz4Walk { u32 exit, nseq, flags; };
-__device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, u32 entry, u32 seg_end, u32 C)
+// Walk from `entry` while the token lies before seg_end.  The set of token positions visited (relative
+// to seg_start, < LZ4W_SEG <= 128) is kept as a bit mask; a re-walk from a new entry stops as soon as it
+// lands on a position the previous walk already visited — from there on the two chains are identical —
+// and inherits the tail.  flags (1 malformed, 2 last sequence of the block) always belong to a walk's
+// final hop, so they travel with the tail.
+struct Lz4Walk { u32 exit, nseq, flags; u64 m0, m1; };
+__device__ __forceinline__ bool mask_test(u64 m0, u64 m1, u32 r) { return ((r < 64 ? m0 >> r : m1 >> (r - 64)) & 1ull) != 0; }
+__device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, u32 entry, u32 seg_start, u32 seg_end, u32 C, const Lz4Walk& old)
 {
-    Lz4Walk w; w.nseq = 0; w.flags = 0;
+    Lz4Walk w; w.nseq = 0; w.flags = 0; w.m0 = 0; w.m1 = 0;
     u32 p = entry;
+    bool merged = false;
     while (p < seg_end) {
-        const Lz4Tok t = lz4_token_at(B, p, C, false);
+        const u32 r = p - seg_start;
+        if (mask_test(old.m0, old.m1, r)) { merged = true; break; }
+        if (r < 64) w.m0 |= 1ull << r; else w.m1 |= 1ull << (r - 64);
+        // tokens of a chunk always lie inside the staged range: one ds_read, no fallback
+        const u32 tok = lds_ld8(B.S + (p - B.cbase));
+        const u32 lit = tok >> 4, mlc = tok & 15;
+        u32 fl = 0, nx;
+        if (lit != 15 && mlc != 15) {                   // no length extension bytes: pure arithmetic
+            const u32 q = p + 1 + lit;
+            if (q >= C) { fl = q == C ? 2u : 1u; nx = C; }
+            else if (C - q < 2) { fl = 1; nx = C; }
+            else nx = q + 2;
+        } else {
+            const Lz4Tok t = lz4_token_at(B, p, C, false);
+            fl = t.flags; nx = t.next;
+        }
         w.nseq++;
-        w.flags |= t.flags;
-        p = t.next;
-        if (t.flags) break;
+        w.flags |= fl;
+        p = nx;
+        if (fl) break;
     }
     w.exit = p;
+    if (merged) {
+        const u32 r = p - seg_start;
+        const u64 t0 = r < 64 ? old.m0 & ~((1ull << r) - 1) : 0ull;
+        const u64 t1 = r < 64 ? old.m1 : old.m1 & ~((1ull << (r - 64)) - 1);
+        w.m0 |= t0; w.m1 |= t1;
+        w.nseq += (u32)(__popcll(t0) + __popcll(t1));
+        w.flags |= old.flags;
+        w.exit = old.exit;
+    }
     return w;
 }
 
@@ -152,24 +191,28 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         for (u32 i = (u32)lane * 16; i < nst; i += WAVE * 16) {
             const u8* g = ip + cpos + i;
             if (i + 16 <= nst && g + 16 <= rd_hi) { u128 v = ld128(g); __builtin_memcpy(sh.stage + i, &v, 16); }
-            else for (u32 k = i; k < nst && k < i + 16; k++) sh.stage[k] = ip[cpos + k];
+            else for (u32 k = i; k < nst && k < i + 16; k++) sh.stage[k] = ld8(ip + cpos + k);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        Lz4Bytes B; B.S = sh.stage; B.g = ip; B.cbase = cpos; B.cend = cpos + nst;
+        u64 ts = SEQ_T(); stt.t_stage += ts - tp0; stt.chunks++;
+        Lz4Bytes B; B.S = to_lds(sh.stage); B.g = ip; B.cbase = cpos; B.cend = cpos + nst;
         // ---- walks to the fixed point ----
         const u32 my_start = cpos + (u32)lane * LZ4W_SEG;
         const u32 my_end = my_start + LZ4W_SEG < tok_end ? my_start + LZ4W_SEG : tok_end;
         const bool active = my_start < tok_end;
         u32 my_entry = my_start;
-        Lz4Walk w; w.exit = my_start; w.nseq = 0; w.flags = 0;
-        if (active) w = lz4_walk(B, my_entry, my_end, C);
+        Lz4Walk w; w.exit = my_start; w.nseq = 0; w.flags = 0; w.m0 = 0; w.m1 = 0;
+        if (active) w = lz4_walk(B, my_entry, my_start, my_end, C, w);
+        { u64 t2 = SEQ_T(); stt.t_walk1 += t2 - ts; ts = t2; }
         for (int iter = 0; iter < 66; iter++) {
+            stt.fix_iters++;
             u32 e = (u32)__shfl_up((int)w.exit, 1, 64);
             if (lane == 0) e = cpos;
             const bool changed = active && e != my_entry;
             if (__ballot(changed) == 0) break;
-            if (changed) { my_entry = e; w = lz4_walk(B, my_entry, my_end, C); }
+            if (changed) { my_entry = e; w = lz4_walk(B, my_entry, my_start, my_end, C, w); }
         }
+        { u64 t2 = SEQ_T(); stt.t_fix += t2 - ts; ts = t2; }
         // inactive lanes forward the chain position
         if (!active) { w.exit = (u32)__shfl((int)w.exit, 63, 64); }
         const u64 lastmask = __ballot(active);
@@ -184,16 +227,16 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
         const u32 nseq = (u32)__builtin_amdgcn_readlane((int)x, 63);
         if (nseq > LZ4W_MAXREC) return D_MALFORMED;                           // cannot happen: >= 3 bytes per sequence
-        if (active) {
-            u32 k = x - w.nseq, p = my_entry;
-            while (p < my_end) {
-                sh.rec[k++] = (u16)(p - cpos);
-                const Lz4Tok t = lz4_token_at(B, p, C, false);
-                p = t.next;
-                if (t.flags) break;
-            }
+        if (active) {                               // the visited mask IS the list of token positions: no re-walk
+            u32 k = x - w.nseq;
+            const u32 rel0 = my_start - cpos;
+            u64 m = w.m0;
+            while (m) { sh.rec[k++] = (u16)(rel0 + (u32)__ffsll((long long)m) - 1); m &= m - 1; }
+            m = w.m1;
+            while (m) { sh.rec[k++] = (u16)(rel0 + 64 + (u32)__ffsll((long long)m) - 1); m &= m - 1; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        { u64 t2 = SEQ_T(); stt.t_emit += t2 - ts; }
         stt.t_parse += SEQ_T() - tp0;
         // ---- execute, 64 consecutive sequences at a time ----
         for (u32 b0 = 0; b0 < nseq; b0 += WAVE) {
@@ -203,11 +246,19 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             bool bad = false;
             if (lane < cnt) {
                 const u32 p = cpos + sh.rec[b0 + (u32)lane];
-                const Lz4Tok t = lz4_token_at(B, p, C, true);
-                q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
-                bad = (t.flags & 1) || (t.ml && t.off == 0) || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
+                const u32 tok = lds_ld8(B.S + (p - B.cbase));
+                const u32 lit = tok >> 4, mlc = tok & 15;
+                const u32 qq = p + 1 + lit;
+                if (lit != 15 && mlc != 15 && qq + 2 <= B.cend && qq + 2 <= C) {     // common case: 2 LDS reads in all
+                    q.lit = ip + p + 1; q.ll = lit; q.ml = mlc + 4; q.off = lds_ld16(B.S + (qq - B.cbase));
+                    bad = q.off == 0;
+                } else {
+                    const Lz4Tok t = lz4_token_at(B, p, C, true);
+                    q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
+                    bad = (t.flags & 1) || (t.ml && t.off == 0) || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
+                }
             }
-            stt.t_parse += SEQ_T() - tq0;
+            { u64 t2 = SEQ_T(); stt.t_parse += t2 - tq0; stt.t_tok += t2 - tq0; }
             if (__ballot(bad) != 0) {
                 // oversize lengths mean the output slot is too small (or the input is malformed): let the sums decide
                 if (__ballot(lane < cnt && (q.ll > (u64)(oend - op) || q.ml > (u64)(oend - op))) != 0) { op_io = op; return D_DST_FULL; }
@@ -283,7 +334,7 @@ __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, Se
                 u64 n = (u64)(iend - ip); if (n > bsz) n = bsz;
                 bool full = n > (u64)(oend - op);
                 if (full) n = (u64)(oend - op);
-                for (u64 i = lane; i < n; i += WAVE) op[i] = ip[i];
+                for (u64 i = (u64)lane * 16; i < n; i += WAVE * 16) gcopy_upto16(op + i, ip + i, (u32)(n - i < 16 ? n - i : 16));
                 op += n;
                 if (full) { r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r; }
             }
@@ -299,7 +350,7 @@ __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, Se
             u64 n = bsz;
             bool full = n > (u64)(oend - op);
             if (full) n = (u64)(oend - op);
-            for (u64 i = lane; i < n; i += WAVE) op[i] = ip[i];
+            for (u64 i = (u64)lane * 16; i < n; i += WAVE * 16) gcopy_upto16(op + i, ip + i, (u32)(n - i < 16 ? n - i : 16));
             op += n;
             if (full) { r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r; }
         } else {

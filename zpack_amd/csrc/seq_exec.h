@@ -31,8 +31,8 @@ __device__ __forceinline__ void gcopy_upto16(u8* d, const u8* s, u32 n)
     if (n >= 16) { st128(d, ld128(s)); return; }
     if (n & 8) { st64(d, ld64(s)); d += 8; s += 8; }
     if (n & 4) { st32(d, ld32(s)); d += 4; s += 4; }
-    if (n & 2) { u16 v = ld16(s); __builtin_memcpy(d, &v, 2); d += 2; s += 2; }
-    if (n & 1) *d = *s;
+    if (n & 2) { st16(d, ld16(s)); d += 2; s += 2; }
+    if (n & 1) st8(d, ld8(s));
 }
 
 // the same in two halves, so that several chunks can be in flight before the first store
@@ -45,7 +45,7 @@ __device__ __forceinline__ u128 gload_upto16(const u8* s, u32 n)
     const u8* p = s + pos;
     if (n & 4) { t = (u64)ld32(p); sh = 32; p += 4; }
     if (n & 2) { t |= (u64)ld16(p) << sh; sh += 16; p += 2; }
-    if (n & 1) { t |= (u64)(*p) << sh; }
+    if (n & 1) { t |= (u64)ld8(p) << sh; }
     u128 v;
     if (pos) { v.lo = lo; v.hi = t; } else { v.lo = t; v.hi = 0; }
     return v;
@@ -56,8 +56,8 @@ __device__ __forceinline__ void gstore_upto16(u8* d, u128 v, u32 n)
     u64 t = v.lo;
     if (n & 8) { st64(d, v.lo); d += 8; t = v.hi; }
     if (n & 4) { st32(d, (u32)t); d += 4; t >>= 32; }
-    if (n & 2) { u16 h = (u16)t; __builtin_memcpy(d, &h, 2); d += 2; t >>= 16; }
-    if (n & 1) *d = (u8)t;
+    if (n & 2) { st16(d, (u16)t); d += 2; t >>= 16; }
+    if (n & 1) st8(d, (u8)t);
 }
 // up to 64 bytes: every load is issued before the first store (one memory round trip)
 __device__ __forceinline__ void gcopy_upto64(u8* d, const u8* s, u32 n)
@@ -80,7 +80,7 @@ __device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
 }
 
 // developer aid: cycle accounting of the executor (kept in registers; written out only when asked)
-struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; };
+struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; u64 t_stage, t_walk1, t_fix, t_emit, t_tok; u32 fix_iters, chunks; };
 #define SEQ_T() __builtin_amdgcn_s_memtime()
 
 struct SeqBatch {
@@ -109,20 +109,91 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     u8* const ms = o + ll;                        // match start
     const bool has_match = act && ml != 0;
     if (__ballot(has_match && (q.off == 0 || (u64)q.off > (u64)(ms - dst_lo))) != 0) return D_MALFORMED;
+    u64 pending = __ballot(has_match);
 
-    // ---- 2. literals ----
+    // ---- 2. in-batch dependencies: pure cross-lane arithmetic, no memory (positions relative to op) ----
+    const u32 r_ms = (u32)(ms - op), r_me = r_ms + ml;           // this lane's match output [r_ms, r_me)
+    i64 src = (i64)r_ms - (i64)q.off;                             // source start, relative to op (negative = older data)
+    const u32 need_len = ml < q.off ? ml : q.off;                 // bytes not produced by the match itself
+    u64 need = 0;
+    if (pending) {
+        #pragma unroll 1
+        for (int round = 0; round < 6; round++) {
+            // which earlier matches of the batch does [src, src+need_len) touch?  Output ranges are sorted by
+            // lane, so two binary searches over the wave (ds_bpermute, no memory) give the lane interval.
+            need = 0;
+            int inside = -1;                                       // lane whose match holds the whole source
+            const i64 send = src + (i64)need_len;
+            const bool reads_batch = has_match && send > 0;
+            if (__ballot(reads_batch) == 0) break;                 // nobody reads batch output
+            int klo = 0, khi = 0;                                  // klo = first lane with r_me > src; khi = first lane with r_ms >= send
+            #pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const u32 a = (u32)__shfl((int)r_me, klo + step - 1, 64);
+                const u32 b = (u32)__shfl((int)r_ms, khi + step - 1, 64);
+                if ((i64)a <= src) klo += step;
+                if ((i64)b < send) khi += step;
+            }
+            if (reads_batch && klo < khi) {
+                if (khi > lane) khi = lane;
+                const u64 span = (khi >= 64 ? ~0ull : ((1ull << khi) - 1)) & ~((1ull << klo) - 1);
+                need = span & pending;                             // only lanes that actually have a match
+                if (need && (need & (need - 1)) == 0) inside = __ffsll((long long)need) - 1;   // exactly one candidate
+            }
+            // Re-point a source that sits entirely inside the externally-sourced part of ONE earlier match at
+            // that match's own (possibly already re-pointed) source: window[x] == window[x - delta_k] holds
+            // there, and composing deltas halves chain depth per round.  The last sweep never redirects, so
+            // `need` always describes the final source.  Cross-lane reads stay outside divergent control flow.
+            const int probe = inside < 0 ? lane : inside;
+            const u32 kms = (u32)__shfl((int)r_ms, probe, 64);
+            const u32 knl = (u32)__shfl((int)need_len, probe, 64);
+            const i64 my_delta = (i64)r_ms - src;
+            const u32 dlo = (u32)__shfl((int)(u32)(u64)my_delta, probe, 64), dhi = (u32)__shfl((int)(u32)((u64)my_delta >> 32), probe, 64);
+            const i64 kdelta = (i64)(((u64)dhi << 32) | dlo);
+            if (inside >= 0 && !((i64)kms <= src && send <= (i64)kms + (i64)knl)) inside = -1;
+            if (round == 5 || __ballot(inside >= 0) == 0) break;
+            if (inside >= 0) src -= kdelta;
+            stt.redirects += (u32)__popcll(__ballot(inside >= 0));
+        }
+    }
+    const u8* const srcp = op + src;                               // (possibly re-pointed) source of the first need_len bytes
+    const bool self_overlap = ml > need_len;                       // offset < length: the match feeds itself
+    const bool coop = has_match && (ml > 64 || self_overlap);
+    // matches whose whole source is older than this batch go out together with the literals
+    const bool early = has_match && !coop && src + (i64)need_len <= 0;
+    { u64 t1 = SEQ_T(); stt.t_dep += t1 - t0; t0 = t1; }
+
+    // ---- 3. literals + early matches: every load is issued before the first store ----
     if (lit_rle >= 0) {
-        if (__ballot(ll > 64) == 0) { for (u32 c = 0; c < ll; c++) o[c] = (u8)lit_rle; }
+        if (__ballot(ll > 64) == 0) { for (u32 c = 0; c < ll; c++) st8(o + c, (u8)lit_rle); }
         else {
             for (int k = 0; k < cnt; k++) {
                 const u32 n = (u32)__builtin_amdgcn_readlane((int)ll, k);
                 u8* p = (u8*)readlane_ptr(o, k);
-                for (u32 c = lane; c < n; c += WAVE) p[c] = (u8)lit_rle;
+                for (u32 c = lane; c < n; c += WAVE) st8(p + c, (u8)lit_rle);
             }
         }
+        if (early) gcopy_upto64(ms, srcp, ml);
     } else {
         const bool long_lit = ll > 64;
-        if (!long_lit) gcopy_upto64(o, q.lit, ll);
+        const u32 ln = long_lit ? 0u : ll, mn = early ? ml : 0u;
+        u128 a0 = {0, 0}, a1 = {0, 0}, a2 = {0, 0}, a3 = {0, 0}, b0 = {0, 0}, b1 = {0, 0}, b2 = {0, 0}, b3 = {0, 0};
+        if (ln > 0) a0 = gload_upto16(q.lit, ln);
+        if (ln > 16) a1 = gload_upto16(q.lit + 16, ln - 16);
+        if (ln > 32) a2 = gload_upto16(q.lit + 32, ln - 32);
+        if (ln > 48) a3 = gload_upto16(q.lit + 48, ln - 48);
+        if (mn > 0) b0 = gload_upto16(srcp, mn);
+        if (mn > 16) b1 = gload_upto16(srcp + 16, mn - 16);
+        if (mn > 32) b2 = gload_upto16(srcp + 32, mn - 32);
+        if (mn > 48) b3 = gload_upto16(srcp + 48, mn - 48);
+        if (ln > 0) gstore_upto16(o, a0, ln);
+        if (ln > 16) gstore_upto16(o + 16, a1, ln - 16);
+        if (ln > 32) gstore_upto16(o + 32, a2, ln - 32);
+        if (ln > 48) gstore_upto16(o + 48, a3, ln - 48);
+        if (mn > 0) gstore_upto16(ms, b0, mn);
+        if (mn > 16) gstore_upto16(ms + 16, b1, mn - 16);
+        if (mn > 32) gstore_upto16(ms + 32, b2, mn - 32);
+        if (mn > 48) gstore_upto16(ms + 48, b3, mn - 48);
         u64 lm = __ballot(long_lit);
         while (lm) {                              // long runs: whole wave, 16 B per lane
             const int k = __ffsll((long long)lm) - 1;
@@ -134,57 +205,11 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
         }
     }
     wave_mem_fence();
-    u64 pending = __ballot(has_match);
+    u64 done = ~pending | __ballot(early);                         // lanes without a match count as done
+    pending &= ~done;
     { u64 t1 = SEQ_T(); stt.t_lit += t1 - t0; t0 = t1; }
-    if (pending == 0) { op += total; return D_OK; }
-
-    // ---- 3. in-batch dependencies (positions relative to op fit 32 bits) ----
-    const u32 r_ms = (u32)(ms - op), r_me = r_ms + ml;           // this lane's match output [r_ms, r_me)
-    i64 src = (i64)r_ms - (i64)q.off;                             // source start, relative to op (negative = older data)
-    u32 need_len = ml < q.off ? ml : q.off;                       // bytes not produced by the match itself
-    u64 need = 0;
-    #pragma unroll 1
-    for (int round = 0; round < 4; round++) {
-        // which earlier matches of the batch does [src, src+need_len) touch?  Output ranges are sorted by
-        // lane, so two binary searches over the wave (ds_bpermute, no memory) give the lane interval.
-        need = 0;
-        int inside = -1;                                           // lane whose match range contains the whole source
-        const i64 send = src + (i64)need_len;
-        const bool reads_batch = has_match && send > 0;
-        if (__ballot(reads_batch) == 0) break;                     // nobody reads batch output
-        int klo = 0, khi = 0;                                      // klo = first lane with r_me > src; khi = first lane with r_ms >= send
-        #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const u32 a = (u32)__shfl((int)r_me, klo + step - 1, 64);
-            const u32 b = (u32)__shfl((int)r_ms, khi + step - 1, 64);
-            if ((i64)a <= src) klo += step;
-            if ((i64)b < send) khi += step;
-        }
-        if (reads_batch && klo < khi) {
-            if (khi > lane) khi = lane;
-            const u64 span = (khi >= 64 ? ~0ull : ((1ull << khi) - 1)) & ~((1ull << klo) - 1);
-            need = span & pending;                                 // only lanes that actually have a match
-            if (need && (need & (need - 1)) == 0) inside = __ffsll((long long)need) - 1;   // exactly one candidate
-        }
-        {   // cross-lane reads stay outside divergent control flow
-            const int probe = inside < 0 ? lane : inside;
-            const u32 kms = (u32)__shfl((int)r_ms, probe, 64), kme = (u32)__shfl((int)r_me, probe, 64);
-            if (inside >= 0 && !((i64)kms <= src && send <= (i64)kme)) inside = -1;
-        }
-        // re-point sources that sit entirely inside one earlier match at that match's own source; the
-        // last sweep never redirects, so `need` always describes the final source
-        const u32 koff = (u32)__shfl((int)q.off, inside < 0 ? lane : inside, 64);
-        if (round == 3 || __ballot(inside >= 0) == 0) break;
-        if (inside >= 0) src -= (i64)koff;
-        stt.redirects += (u32)__popcll(__ballot(inside >= 0));
-    }
-    { u64 t1 = SEQ_T(); stt.t_dep += t1 - t0; t0 = t1; }
 
     // ---- 4. rounds ----
-    const u8* const srcp = op + src;                               // (possibly re-pointed) source of the first need_len bytes
-    const bool self_overlap = ml > need_len;                       // offset < length: the match feeds itself
-    const bool coop = has_match && (ml > 64 || self_overlap);
-    u64 done = ~__ballot(has_match);                               // lanes without a match count as done
     u32 guard = 0;
     while (pending) {
         const bool ready = has_match && ((pending >> lane) & 1) && (need & ~done) == 0;
@@ -212,7 +237,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
                     wave_mem_fence();
                 }
             } else {
-                for (u32 c = lane; c < n; c += WAVE) p[c] = m[c % koff];
+                for (u32 c = lane; c < n; c += WAVE) st8(p + c, ld8(m + c % koff));
             }
         }
         wave_mem_fence();

@@ -64,7 +64,7 @@ __device__ inline u64 xxh3_short(const u8* in, u32 len)
 {
     if (len == 0) return xxh64_avalanche(sec64(56) ^ sec64(64));
     if (len <= 3) {
-        u32 c1 = in[0], c2 = in[len >> 1], c3 = in[len - 1];
+        u32 c1 = ld8(in), c2 = ld8(in + (len >> 1)), c3 = ld8(in + len - 1);
         u32 combined = (c1 << 16) | (c2 << 24) | c3 | (len << 8);
         u64 flip = (u64)(sec32(0) ^ sec32(4));
         return xxh64_avalanche((u64)combined ^ flip);
@@ -230,7 +230,7 @@ __device__ inline u32 xxh32_serial(const u8* p, u64 len, u32 seed)
     }
     h += (u32)len;
     while (p + 4 <= end) { h = rotl32(h + ld32(p) * ZPK_P32_3, 17) * ZPK_P32_4; p += 4; }
-    while (p < end) { h = rotl32(h + (u32)(*p) * ZPK_P32_5, 11) * ZPK_P32_1; p++; }
+    while (p < end) { h = rotl32(h + (u32)ld8(p) * ZPK_P32_5, 11) * ZPK_P32_1; p++; }
     h ^= h >> 15; h *= ZPK_P32_2; h ^= h >> 13; h *= ZPK_P32_3; h ^= h >> 16;
     return h;
 }
@@ -259,7 +259,7 @@ __device__ inline u64 xxh64_serial(const u8* p, u64 len, u64 seed)
     h += len;
     while (p + 8 <= end) { h ^= xxh64_round(0, ld64(p)); h = rotl64(h, 27) * ZPK_P64_1 + ZPK_P64_4; p += 8; }
     if (p + 4 <= end) { h ^= (u64)ld32(p) * ZPK_P64_1; h = rotl64(h, 23) * ZPK_P64_2 + ZPK_P64_3; p += 4; }
-    while (p < end) { h ^= (u64)(*p) * ZPK_P64_5; h = rotl64(h, 11) * ZPK_P64_1; p++; }
+    while (p < end) { h ^= (u64)ld8(p) * ZPK_P64_5; h = rotl64(h, 11) * ZPK_P64_1; p++; }
     return xxh64_avalanche(h);
 }
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
         const u64 len = uni64(d.uncomp_size);
         u64 h;
         if (len <= 240) {
-            for (u64 i = lane; i < len; i += WAVE) out[i] = in[i];
+            for (u64 i = lane; i < len; i += WAVE) st8(out + i, ld8(in + i));
             h = 0;
             lane0_guard();
             if (lane == 0) h = xxh3_short(in, (u32)len);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
                 cur = nxt;
             }
             const u64 done = nblocks << 10;
-            for (u64 i = done + lane; i < len; i += WAVE) out[i] = in[i];
+            for (u64 i = done + lane; i < len; i += WAVE) st8(out + i, ld8(in + i));
             const u32 nstripes = (u32)(((len - 1) - done) >> 6);
             h = st.finish(in + done, nstripes, in + len, len, lane);
         }
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
 __global__ __launch_bounds__(64) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
-                                                  const u32* __restrict__ counters, u64* __restrict__ dbg)
+                                                  const u32* __restrict__ counters, u64* __restrict__ dbg, int getenv_dbg2)
 {
     const int lane = lane_id();
     __shared__ Lz4WaveShared shw;
@@ -162,6 +162,8 @@ __global__ __launch_bounds__(64) void k_lz4_wave(const u8* __restrict__ src, con
             u64* g = dbg + (u64)e * 8;
             g[0] = stt.t_parse; g[1] = stt.t_lit; g[2] = stt.t_dep; g[3] = stt.t_rounds;
             g[4] = ((u64)stt.batches << 32) | stt.rounds; g[5] = ((u64)stt.coops << 32) | stt.redirects; g[6] = SEQ_T() - t_all;
+            g[7] = ((u64)stt.fix_iters << 32) | stt.chunks;
+            if (getenv_dbg2) { g[0] = stt.t_stage; g[1] = stt.t_walk1; g[2] = stt.t_fix; g[3] = stt.t_emit; g[4] = stt.t_tok; }
         }
         // lib/zpack_read.c:421-450
         int status = R_OK;
@@ -330,7 +332,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_TRACE_STEP("k_stored");
     ZPK_KEV(ZPK_K_LZ4, 0);
     if (!(skip & 2)) hipLaunchKernelGGL(k_lz4_wave, dim3((u32)n), dim3(64), 0, st, src, read_lo, read_hi, desc, dst, res,
-                       c->d_lists + L_LZ4 * stride, c->d_counters, c->d_dbg);
+                       c->d_lists + L_LZ4 * stride, c->d_counters, c->d_dbg, want_dbg == 2 ? 1 : 0);
     ZPK_KEV(ZPK_K_LZ4, 1);
     ZPK_TRACE_STEP("k_lz4_wave");
     ZPK_KEV(ZPK_K_ZSTD, 0);

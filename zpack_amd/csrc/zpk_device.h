@@ -51,19 +51,51 @@ template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) { return (T*)u
 // wave barrier is a convergent no-op, and LLVM never duplicates a block that holds one.
 __device__ __forceinline__ void lane0_guard() { __builtin_amdgcn_wave_barrier(); }
 
-// unaligned loads/stores: gfx950 runs in unaligned-access mode, hipcc lowers these to single
-// global_load_dword[x2|x4] / ds_read_b32 instructions (checked in the ISA).
-__device__ __forceinline__ u16 ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
-__device__ __forceinline__ u32 ld32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
-__device__ __forceinline__ u64 ld64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+// Address spaces.  A `const u8*` that went through readfirstlane (uni_ptr) or a pointer select is a
+// GENERIC pointer to the compiler, and every access through it becomes a FLAT instruction — an order of
+// magnitude slower than ds_read for LDS and tied to both vmcnt and lgkmcnt (measured: the LZ4 walk ran
+// ~1000 cycles per token on flat loads).  So: every helper below that takes a plain pointer means HBM
+// (global) and says so to the compiler; LDS is only ever touched through array indexing on __shared__
+// objects or through the lds_* helpers.
+#define ZPK_GLOBAL __attribute__((address_space(1)))
+#define ZPK_LDS __attribute__((address_space(3)))
+struct __attribute__((packed, aligned(1))) pk16 { u16 v; };
+struct __attribute__((packed, aligned(1))) pk32 { u32 v; };
+struct __attribute__((packed, aligned(1))) pk64 { u64 v; };
 struct __attribute__((packed, aligned(1))) u128 { u64 lo, hi; };
-__device__ __forceinline__ u128 ld128(const u8* p) { u128 v; __builtin_memcpy(&v, p, 16); return v; }
-__device__ __forceinline__ void st128(u8* p, u128 v) { __builtin_memcpy(p, &v, 16); }
-__device__ __forceinline__ void st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
-__device__ __forceinline__ void st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
+
+// unaligned global loads/stores: gfx950 runs in unaligned-access mode, these are single
+// global_load/store_{ubyte,ushort,dword,dwordx2,dwordx4} instructions (checked in the ISA)
+__device__ __forceinline__ u8   ld8(const u8* p)   { return *(const ZPK_GLOBAL u8*)p; }
+__device__ __forceinline__ u16  ld16(const u8* p)  { return ((const ZPK_GLOBAL pk16*)p)->v; }
+__device__ __forceinline__ u32  ld32(const u8* p)  { return ((const ZPK_GLOBAL pk32*)p)->v; }
+__device__ __forceinline__ u64  ld64(const u8* p)  { return ((const ZPK_GLOBAL pk64*)p)->v; }
+typedef u32 v4u32 __attribute__((ext_vector_type(4)));
+typedef v4u32 __attribute__((aligned(1))) v4u32_u;
+__device__ __forceinline__ u128 ld128(const u8* p)
+{
+    const v4u32 x = *(const ZPK_GLOBAL v4u32_u*)p;
+    u128 r; r.lo = ((u64)x.y << 32) | x.x; r.hi = ((u64)x.w << 32) | x.z;
+    return r;
+}
+__device__ __forceinline__ void st8(u8* p, u8 v)     { *(ZPK_GLOBAL u8*)p = v; }
+__device__ __forceinline__ void st16(u8* p, u16 v)   { ((ZPK_GLOBAL pk16*)p)->v = v; }
+__device__ __forceinline__ void st32(u8* p, u32 v)   { ((ZPK_GLOBAL pk32*)p)->v = v; }
+__device__ __forceinline__ void st64(u8* p, u64 v)   { ((ZPK_GLOBAL pk64*)p)->v = v; }
+__device__ __forceinline__ void st128(u8* p, u128 v)
+{
+    v4u32 x; x.x = (u32)v.lo; x.y = (u32)(v.lo >> 32); x.z = (u32)v.hi; x.w = (u32)(v.hi >> 32);
+    *(ZPK_GLOBAL v4u32_u*)p = x;
+}
+
+// LDS accessors for code that only has a generic pointer to a __shared__ object
+typedef const ZPK_LDS u8* lds_cp8;
+__device__ __forceinline__ lds_cp8 to_lds(const u8* p) { return (lds_cp8)p; }
+__device__ __forceinline__ u32 lds_ld8(lds_cp8 p)  { return (u32)*p; }
+__device__ __forceinline__ u32 lds_ld16(lds_cp8 p) { return (u32)((const ZPK_LDS pk16*)p)->v; }
 
 // uniform byte / halfword / word reads: one lane-0 style load broadcast through an SGPR
-__device__ __forceinline__ u32 uld8(const u8* p) { return uni((u32)*p); }
+__device__ __forceinline__ u32 uld8(const u8* p) { return uni((u32)ld8(p)); }
 __device__ __forceinline__ u32 uld16(const u8* p) { return uni((u32)ld16(p)); }
 __device__ __forceinline__ u32 uld32(const u8* p) { return uni(ld32(p)); }
 
