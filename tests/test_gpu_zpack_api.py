@@ -1,0 +1,213 @@
+"""The reference's own three test programs (tests/open_archive.c, tests/read_archive.c, tests/write_archive.c),
+re-stated against libzpack_amd.so through the zpack.h ABI — same flow, same buffer sizes (350-byte output
+buffer, 16-byte streaming input window), same golden archives.  write_archive is checked harder than the
+reference does (it only looks at return codes): every archive written here must read back bit-exactly
+through the oracle decoders (and through the compiled reference where it is present)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import zpack_amd
+from benchdata import datagen as dg
+from tests import zpk
+from tests._libs import (ZPackAPI, Reader, Writer, Stream, File, CompressOptions, FileEntry, u8p, oracle, have_ref, ref,
+                         METHOD_NONE, METHOD_ZSTD, METHOD_LZ4)
+
+pytestmark = pytest.mark.gpu
+
+ARCHIVES = ["archive_none.zpk", "archive_zstd.zpk", "archive_lz4.zpk"]
+FILES = ["file1.txt", "file2.txt"]
+HASHES = [0x7874cba47d02b07d, 0x15f25c0f24dd8e52]          # /root/reference/tests/archive.h:112-115
+BUFFER_SIZE, STREAM_IN_SIZE = 350, 16                       # tests/read_archive.c:11-13
+
+
+@pytest.fixture(scope="module")
+def Z():
+    return ZPackAPI(zpack_amd.ZPACK_SO)
+
+
+def _wd(golden_dir, name):
+    return os.path.join(golden_dir, "ref_workdir", name)
+
+
+def _open_three_ways(Z, golden_dir, arc):
+    """file reader, copied-buffer reader, shared-buffer reader (tests/open_archive.c:59,72,85)"""
+    raw = open(_wd(golden_dir, arc), "rb").read()
+    keep = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+    for how in ("file", "copy", "shared"):
+        r = Reader()
+        if how == "file":
+            rc = Z.lib.zpack_init_reader(C.byref(r), _wd(golden_dir, arc).encode())
+        elif how == "copy":
+            rc = Z.lib.zpack_init_reader_memory(C.byref(r), C.cast(keep, u8p), len(raw))
+        else:
+            rc = Z.lib.zpack_init_reader_memory_shared(C.byref(r), C.cast(keep, u8p), len(raw))
+        assert rc == 0, (arc, how, rc)
+        yield how, r
+        Z.lib.zpack_close_reader(C.byref(r))
+        assert bytes(r) == bytes(C.sizeof(Reader))          # close re-zeroes the struct (lib/zpack_read.c:692-717)
+
+
+@pytest.mark.parametrize("arc", ARCHIVES)
+def test_open_archive(Z, golden_dir, arc):
+    for how, r in _open_three_ways(Z, golden_dir, arc):
+        assert r.file_count == 2 and r.version == 1
+        for i, e in enumerate(Z.entries(r)):
+            plain = open(_wd(golden_dir, FILES[i]), "rb").read()
+            assert e["filename"] == FILES[i] and e["uncomp_size"] == len(plain) and e["hash"] == HASHES[i]
+
+
+@pytest.mark.parametrize("arc", ARCHIVES)
+def test_read_archive_oneshot_and_streaming(Z, golden_dir, arc):
+    for how, r in _open_three_ways(Z, golden_dir, arc):
+        # ---- one-shot (tests/read_archive.c:21-35)
+        for i in range(2):
+            plain = open(_wd(golden_dir, FILES[i]), "rb").read()
+            rc, out = Z.read_file(r, i, BUFFER_SIZE)
+            assert rc == 0, (arc, how, i, rc, r.last_return)
+            assert out[:len(plain)] == plain
+        # ---- streaming with a 16-byte input window (tests/read_archive.c:38-82)
+        st = Stream()
+        assert Z.lib.zpack_init_stream(C.byref(st)) == 0
+        in_buf = (C.c_uint8 * STREAM_IN_SIZE)()
+        for i in range(2):
+            plain = open(_wd(golden_dir, FILES[i]), "rb").read()
+            out = (C.c_uint8 * BUFFER_SIZE)()
+            Z.lib.zpack_reset_stream(C.byref(st))
+            st.next_out = C.cast(out, u8p)
+            st.avail_out = BUFFER_SIZE
+            e = r.file_entries[i]
+            for passes in range(10000):
+                if st.read_back:
+                    tail = C.string_at(C.addressof(st.next_in.contents) - st.read_back, st.read_back)
+                    C.memmove(in_buf, tail, st.read_back)
+                st.next_in = C.cast(in_buf, u8p)
+                st.avail_in = STREAM_IN_SIZE
+                st.avail_out = BUFFER_SIZE
+                rc = Z.lib.zpack_read_file_stream(C.byref(r), C.byref(e), C.byref(st), None)
+                assert rc == 0, (arc, how, i, passes, rc)
+                if st.total_in == e.comp_size and st.read_back == 0:
+                    break
+            else:
+                raise AssertionError("stream never finished")
+            assert bytes(out[:len(plain)]) == plain and st.total_out == len(plain)
+        Z.lib.zpack_close_stream(C.byref(st))
+
+
+def _decode_all_with_checkers(arc_bytes, want):
+    """every entry of an archive we wrote must decode bit-exactly with the oracle, and with the compiled reference if present"""
+    o = oracle()
+    ents = zpk.parse(arc_bytes)
+    assert [e["filename"] for e in ents] == [n for n, _ in want]
+    for e, (name, data) in zip(ents, want):
+        assert e["uncomp_size"] == len(data) and e["hash"] == dg.xxh3(data)
+        rc, out, got, h = o.entry_decode(arc_bytes, e["offset"], e["comp_size"], e["uncomp_size"], e["hash"], e["method"], len(data))
+        assert rc == 0 and out == data, (name, rc)
+    if have_ref():
+        R = ref()
+        rc, r, keep = R.open_memory(arc_bytes)
+        assert rc == 0
+        for i, (name, data) in enumerate(want):
+            rc, out = R.read_file(r, i, len(data))
+            assert rc == 0 and out == data, ("reference rejects our archive", name, rc)
+        R.close_reader(r)
+
+
+@pytest.mark.parametrize("method,level", [(METHOD_ZSTD, 3), (METHOD_LZ4, 1), (METHOD_NONE, 0)])   # tests/write_archive.c:31-41
+@pytest.mark.parametrize("sink", ["file", "heap"])
+def test_write_archive_oneshot_and_streaming(Z, golden_dir, tmp_path, method, level, sink):
+    want = [(n, open(_wd(golden_dir, n), "rb").read()) for n in FILES]
+    # ---- one-shot (tests/write_archive.c:112-191 -> zpack_write_archive)
+    w = Writer()
+    path = str(tmp_path / "out.zpk")
+    rc = Z.lib.zpack_init_writer(C.byref(w), path.encode()) if sink == "file" else Z.lib.zpack_init_writer_heap(C.byref(w), 0)
+    assert rc == 0
+    opts = CompressOptions(method, level)
+    arr = (File * 2)()
+    keep = []
+    for i, (n, data) in enumerate(want):
+        b = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        keep.append(b)
+        arr[i].filename = n.encode(); arr[i].buffer = C.cast(b, u8p); arr[i].size = len(data); arr[i].options = C.pointer(opts)
+    rc = Z.lib.zpack_write_archive(C.byref(w), arr, 2)
+    assert rc == 0, (rc, w.last_return)
+    if sink == "heap":
+        arc = bytes(C.cast(w.buffer, C.POINTER(C.c_uint8 * w.file_size)).contents)
+    Z.lib.zpack_close_writer(C.byref(w))
+    if sink == "file":
+        arc = open(path, "rb").read()
+    _decode_all_with_checkers(arc, want)
+
+    # ---- streaming in 16-byte chunks (tests/write_archive.c:45-110)
+    w = Writer()
+    path = str(tmp_path / "out_s.zpk")
+    rc = Z.lib.zpack_init_writer(C.byref(w), path.encode()) if sink == "file" else Z.lib.zpack_init_writer_heap(C.byref(w), 0)
+    assert rc == 0
+    assert Z.lib.zpack_write_header(C.byref(w)) == 0 and Z.lib.zpack_write_data_header(C.byref(w)) == 0
+    st = Stream()
+    assert Z.lib.zpack_init_stream(C.byref(st)) == 0
+    out_size = Z.lib.zpack_get_cstream_out_size(METHOD_NONE)
+    out_buf = (C.c_uint8 * out_size)()
+    st.next_out = C.cast(out_buf, u8p); st.avail_out = out_size
+    for i, (n, data) in enumerate(want):
+        Z.lib.zpack_reset_stream(C.byref(st))
+        st.next_in = arr[i].buffer
+        while st.total_in < len(data):
+            st.avail_in = min(STREAM_IN_SIZE, len(data) - st.total_in)
+            assert Z.lib.zpack_write_file_stream(C.byref(w), C.byref(opts), C.byref(st), None) == 0
+        assert Z.lib.zpack_write_file_stream_end(C.byref(w), n.encode(), C.byref(opts), C.byref(st), None) == 0
+    Z.lib.zpack_close_stream(C.byref(st))
+    assert Z.lib.zpack_write_cdr(C.byref(w)) == 0 and Z.lib.zpack_write_eocdr(C.byref(w)) == 0
+    if sink == "heap":
+        arc2 = bytes(C.cast(w.buffer, C.POINTER(C.c_uint8 * w.file_size)).contents)
+    Z.lib.zpack_close_writer(C.byref(w))
+    if sink == "file":
+        arc2 = open(path, "rb").read()
+    _decode_all_with_checkers(arc2, want)
+    assert arc2 == arc                                           # same container either way
+
+
+@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 3), (METHOD_NONE, 0)])
+def test_batch_write_then_batch_read_roundtrip(Z, method, level):
+    """zpack_write_files (n files, one device batch) then the additive zpack_read_files / _packed."""
+    rng = np.random.default_rng(5)
+    sizes = [0, 1, 11, 12, 13, 200, 4095, 65535, 65536, 65537, 200000, 1 << 20] + [int(x) for x in rng.integers(1, 150000, 40)]
+    want = [("f%03d" % i, dg.fill(i % 4, 77, i, n).tobytes()) for i, n in enumerate(sizes)]
+    arc = Z.write_archive(want, method, level)
+    _decode_all_with_checkers(arc, want)
+    if method == METHOD_LZ4:                                     # the device compressor must actually compress text / records / runs
+        ents = zpk.parse(arc)
+        for e, (n, d) in zip(ents, want):
+            if len(d) >= 4095 and int(n[1:]) % 4 != dg.RANDOM:
+                assert e["comp_size"] < 0.92 * len(d), (n, e["comp_size"], len(d))
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    n = r.file_count
+    ptrs = (C.POINTER(FileEntry) * n)(*[C.pointer(r.file_entries[i]) for i in range(n)])
+    Z.lib.zpack_read_files.argtypes = [C.POINTER(Reader), C.POINTER(C.POINTER(FileEntry)), C.c_uint64, C.POINTER(u8p),
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.c_void_p]
+    outs = [(C.c_uint8 * max(1, len(d)))() for _, d in want]
+    bufs = (u8p * n)(*[C.cast(o, u8p) for o in outs])
+    caps = (C.c_size_t * n)(*[len(d) for _, d in want])
+    results = (C.c_int * n)()
+    assert Z.lib.zpack_read_files(C.byref(r), ptrs, n, bufs, caps, results, None) == 0
+    for i, (name, d) in enumerate(want):
+        assert results[i] == 0, (name, results[i])
+        assert bytes(outs[i][:len(d)]) == d
+    # packed form
+    Z.lib.zpack_read_files_packed.argtypes = [C.POINTER(Reader), C.POINTER(C.POINTER(FileEntry)), C.c_uint64, u8p, C.c_size_t,
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.c_void_p]
+    total = sum(len(d) for _, d in want)
+    big = (C.c_uint8 * total)()
+    offs = (C.c_uint64 * n)()
+    assert Z.lib.zpack_read_files_packed(C.byref(r), ptrs, n, C.cast(big, u8p), total, offs, results, None) == 0
+    blob = bytes(big)
+    for i, (name, d) in enumerate(want):
+        assert results[i] == 0 and blob[offs[i]:offs[i] + len(d)] == d
+    # one bad entry must not poison the batch: corrupt entry 5's hash
+    r.file_entries[5].hash ^= 1
+    assert Z.lib.zpack_read_files(C.byref(r), ptrs, n, bufs, caps, results, None) == 0
+    assert results[5] == 15 and all(results[i] == 0 for i in range(n) if i != 5 and len(want[i][1]))
+    Z.close_reader(r)

@@ -51,7 +51,7 @@ def build_zpack(force=False, verbose=False):
     deps = csrcs + [os.path.join(ROOT, "include", "zpack.h"), os.path.join(ROOT, "include", "zpack_codec.h"), CODEC_SO]
     if not force and not _newer(ZPACK_SO, deps):
         return ZPACK_SO
-    cmd = ["gcc", "-O2", "-g", "-fPIC", "-shared", "-std=c11", "-Wall", "-Wextra", "-D_FILE_OFFSET_BITS=64",
+    cmd = ["gcc", "-O2", "-g", "-fPIC", "-shared", "-std=c11", "-Wall", "-Wextra", "-D_FILE_OFFSET_BITS=64", "-D_POSIX_C_SOURCE=200809L", "-fvisibility=hidden",
            "-I" + os.path.join(ROOT, "include"), "-o", ZPACK_SO] + csrcs + \
           ["-L" + HERE, "-lzpk_codec", "-Wl,-rpath,$ORIGIN"]
     if verbose:

@@ -18,6 +18,7 @@
 #include "zpk_device.h"
 #include "xxh3_device.h"
 #include "lz4_wave.h"      // ByteWindow, DecodeOut
+#include "seq_exec.h"
 
 namespace zpk {
 
@@ -594,25 +595,21 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
                 ell = lds_entry(sh.ll, sll); eml = lds_entry(sh.ml, sml); eof_ = lds_entry(sh.of, sof);
                 if (lane == k) { my_ll = ll; my_ml = ml; my_off = offset; }
             }
-            // ---- execute the batch in order: literal run, then match, each by all 64 lanes
-            for (int k = 0; k < cnt; k++) {
-                if (fs.wd->expired()) return D_MALFORMED;
-                const u64 ll = (u32)__builtin_amdgcn_readlane((int)my_ll, k);
-                const u64 ml = (u32)__builtin_amdgcn_readlane((int)my_ml, k);
-                const u64 off = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(my_off >> 32), k) << 32) |
-                                (u32)__builtin_amdgcn_readlane((int)(u32)my_off, k);
-                if (ll + ml > (u64)(oend - op)) { produced = (u64)(op - dst); return D_DST_FULL; }
-                if (ll > lit_size - lit_pos) return D_MALFORMED;
-                if (lit_rle) { for (u64 i = lane; i < ll; i += WAVE) op[i] = (u8)lit_rle_byte; }
-                else { for (u64 i = lane; i < ll; i += WAVE) op[i] = lit[lit_pos + i]; }
-                op += ll; lit_pos += ll;
-                if (off > (u64)(op - frame_lo)) return D_MALFORMED;
-                wave_mem_fence();
-                const u8* m = op - off;
-                if (off >= ml) { for (u64 i = lane; i < ml; i += WAVE) op[i] = m[i]; }
-                else { for (u64 i = lane; i < ml; i += WAVE) op[i] = m[i % off]; }
-                wave_mem_fence();
-                op += ml;
+            // ---- execute the batch lane-parallel (seq_exec.h): literal sources are a prefix sum over the literal buffer
+            {
+                u32 xl = lane < cnt ? my_ll : 0u;
+                #pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)xl, d, 64); if (lane >= d) xl += y; }
+                const u64 lit_total = (u32)__builtin_amdgcn_readlane((int)xl, 63);
+                if (lit_total > lit_size - lit_pos) return D_MALFORMED;
+                if (__ballot(lane < cnt && (my_off == 0 || my_off > 0xFFFFFFFFull)) != 0) return D_MALFORMED;
+                SeqBatch q;
+                q.lit = lit + lit_pos + (xl - (lane < cnt ? my_ll : 0u));
+                q.ll = my_ll; q.ml = my_ml; q.off = (u32)my_off;
+                SeqStats stt = {};
+                const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt);
+                if (rc != D_OK) { produced = (u64)(op - dst); return rc; }
+                lit_pos += lit_total;
             }
         }
         if (b.pos > 0) return D_MALFORMED;           // libzstd 1.4.9: the stream must not be under-consumed
