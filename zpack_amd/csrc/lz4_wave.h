@@ -65,9 +65,20 @@ struct DecodeOut { int rc; u64 produced; };
 #define LZ4W_MAXREC (LZ4W_CHUNK / 3u + 64u)
 
 struct alignas(16) Lz4WaveShared {
-    u8  stage[LZ4W_CHUNK + LZ4W_SLACK];
-    u16 rec[LZ4W_MAXREC];
+    u8  stage[LZ4W_CHUNK + LZ4W_SLACK];          // 5.4 KiB per wave: the only LDS this kernel uses
 };
+
+// r-th (0-based) set bit of w; r < popcount(w)
+__device__ __forceinline__ u32 nth_set_bit(u64 w, u32 r)
+{
+    u32 pos = 0;
+    #pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const u32 c = (u32)__popcll((w >> pos) & ((1ull << sh) - 1));
+        if (r >= c) { r -= c; pos += (u32)sh; }
+    }
+    return pos;
+}
 
 // byte `pos` of the block: from the staged chunk when it is there, else from memory (only a sequence
 // whose literal run crosses the end of the chunk gets there)
@@ -226,16 +237,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
         const u32 nseq = (u32)__builtin_amdgcn_readlane((int)x, 63);
-        if (nseq > LZ4W_MAXREC) return D_MALFORMED;                           // cannot happen: >= 3 bytes per sequence
-        if (active) {                               // the visited mask IS the list of token positions: no re-walk
-            u32 k = x - w.nseq;
-            const u32 rel0 = my_start - cpos;
-            u64 m = w.m0;
-            while (m) { sh.rec[k++] = (u16)(rel0 + (u32)__ffsll((long long)m) - 1); m &= m - 1; }
-            m = w.m1;
-            while (m) { sh.rec[k++] = (u16)(rel0 + 64 + (u32)__ffsll((long long)m) - 1); m &= m - 1; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const u32 my_nseq = active ? w.nseq : 0u;
         { u64 t2 = SEQ_T(); stt.t_emit += t2 - ts; }
         stt.t_parse += SEQ_T() - tp0;
         // ---- execute, 64 consecutive sequences at a time ----
@@ -244,8 +246,24 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             const u64 tq0 = SEQ_T();
             SeqBatch q; q.lit = ip; q.ll = 0; q.ml = 0; q.off = 1;
             bool bad = false;
+            // sequence number -> token position without a table: the owning segment by binary search over the
+            // wave's prefix sums, then the rank-th set bit of that lane's visited mask (all ds_bpermute + ALU)
+            const u32 sq = b0 + (u32)lane;
+            int own = 0;
+            #pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const u32 v = (u32)__shfl((int)x, own + step - 1, 64);
+                if (v <= sq) own += step;
+            }
+            if (own > 63) own = 63;
+            const u32 ox = (u32)__shfl((int)x, own, 64), on = (u32)__shfl((int)my_nseq, own, 64);
+            const u32 ostart = (u32)__shfl((int)my_start, own, 64);
+            const u64 om0 = ((u64)(u32)__shfl((int)(u32)(w.m0 >> 32), own, 64) << 32) | (u32)__shfl((int)(u32)w.m0, own, 64);
+            const u64 om1 = ((u64)(u32)__shfl((int)(u32)(w.m1 >> 32), own, 64) << 32) | (u32)__shfl((int)(u32)w.m1, own, 64);
             if (lane < cnt) {
-                const u32 p = cpos + sh.rec[b0 + (u32)lane];
+                u32 rk = sq - (ox - on);
+                const u32 c0 = (u32)__popcll(om0);
+                const u32 p = rk < c0 ? ostart + nth_set_bit(om0, rk) : ostart + 64 + nth_set_bit(om1, rk - c0);
                 const u32 tok = lds_ld8(B.S + (p - B.cbase));
                 const u32 lit = tok >> 4, mlc = tok & 15;
                 const u32 qq = p + 1 + lit;

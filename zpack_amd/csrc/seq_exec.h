@@ -73,6 +73,15 @@ __device__ __forceinline__ void gcopy_upto64(u8* d, const u8* s, u32 n)
     if (n > 48) gstore_upto16(d + 48, v3, n - 48);
 }
 
+__device__ __forceinline__ void gcopy_upto32(u8* d, const u8* s, u32 n)
+{
+    u128 v0 = {0, 0}, v1 = {0, 0};
+    if (n > 0) v0 = gload_upto16(s, n);
+    if (n > 16) v1 = gload_upto16(s + 16, n - 16);
+    if (n > 0) gstore_upto16(d, v0, n);
+    if (n > 16) gstore_upto16(d + 16, v1, n - 16);
+}
+
 __device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
 {
     return (const u8*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)p >> 32), k) << 32) |
@@ -82,6 +91,10 @@ __device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
 // developer aid: cycle accounting of the executor (kept in registers; written out only when asked)
 struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; u64 t_stage, t_walk1, t_fix, t_emit, t_tok; u32 fix_iters, chunks; };
 #define SEQ_T() __builtin_amdgcn_s_memtime()
+
+// a lane copies its own literal run / match only up to this many bytes (register budget: 2 x 16 B per kind);
+// longer ones are copied by the whole wave
+#define SEQ_OWN_MAX 32u
 
 struct SeqBatch {
     const u8* lit;     // literal source of this lane's sequence (ignored when lit_rle)
@@ -158,14 +171,14 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     }
     const u8* const srcp = op + src;                               // (possibly re-pointed) source of the first need_len bytes
     const bool self_overlap = ml > need_len;                       // offset < length: the match feeds itself
-    const bool coop = has_match && (ml > 64 || self_overlap);
+    const bool coop = has_match && (ml > SEQ_OWN_MAX || self_overlap);
     // matches whose whole source is older than this batch go out together with the literals
     const bool early = has_match && !coop && src + (i64)need_len <= 0;
     { u64 t1 = SEQ_T(); stt.t_dep += t1 - t0; t0 = t1; }
 
     // ---- 3. literals + early matches: every load is issued before the first store ----
     if (lit_rle >= 0) {
-        if (__ballot(ll > 64) == 0) { for (u32 c = 0; c < ll; c++) st8(o + c, (u8)lit_rle); }
+        if (__ballot(ll > SEQ_OWN_MAX) == 0) { for (u32 c = 0; c < ll; c++) st8(o + c, (u8)lit_rle); }
         else {
             for (int k = 0; k < cnt; k++) {
                 const u32 n = (u32)__builtin_amdgcn_readlane((int)ll, k);
@@ -173,27 +186,19 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
                 for (u32 c = lane; c < n; c += WAVE) st8(p + c, (u8)lit_rle);
             }
         }
-        if (early) gcopy_upto64(ms, srcp, ml);
+        if (early) gcopy_upto32(ms, srcp, ml);
     } else {
-        const bool long_lit = ll > 64;
+        const bool long_lit = ll > SEQ_OWN_MAX;
         const u32 ln = long_lit ? 0u : ll, mn = early ? ml : 0u;
-        u128 a0 = {0, 0}, a1 = {0, 0}, a2 = {0, 0}, a3 = {0, 0}, b0 = {0, 0}, b1 = {0, 0}, b2 = {0, 0}, b3 = {0, 0};
+        u128 a0 = {0, 0}, a1 = {0, 0}, b0 = {0, 0}, b1 = {0, 0};
         if (ln > 0) a0 = gload_upto16(q.lit, ln);
         if (ln > 16) a1 = gload_upto16(q.lit + 16, ln - 16);
-        if (ln > 32) a2 = gload_upto16(q.lit + 32, ln - 32);
-        if (ln > 48) a3 = gload_upto16(q.lit + 48, ln - 48);
         if (mn > 0) b0 = gload_upto16(srcp, mn);
         if (mn > 16) b1 = gload_upto16(srcp + 16, mn - 16);
-        if (mn > 32) b2 = gload_upto16(srcp + 32, mn - 32);
-        if (mn > 48) b3 = gload_upto16(srcp + 48, mn - 48);
         if (ln > 0) gstore_upto16(o, a0, ln);
         if (ln > 16) gstore_upto16(o + 16, a1, ln - 16);
-        if (ln > 32) gstore_upto16(o + 32, a2, ln - 32);
-        if (ln > 48) gstore_upto16(o + 48, a3, ln - 48);
         if (mn > 0) gstore_upto16(ms, b0, mn);
         if (mn > 16) gstore_upto16(ms + 16, b1, mn - 16);
-        if (mn > 32) gstore_upto16(ms + 32, b2, mn - 32);
-        if (mn > 48) gstore_upto16(ms + 48, b3, mn - 48);
         u64 lm = __ballot(long_lit);
         while (lm) {                              // long runs: whole wave, 16 B per lane
             const int k = __ffsll((long long)lm) - 1;
@@ -216,7 +221,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
         const u64 rmask = __ballot(ready);
         if (rmask == 0 || ++guard > 70) return D_MALFORMED;        // cannot happen: the lowest pending lane is always ready
         stt.rounds++;
-        if (ready && !coop) gcopy_upto64(ms, srcp, ml);            // whole source final and not produced by this match
+        if (ready && !coop) gcopy_upto32(ms, srcp, ml);            // whole source final and not produced by this match
         u64 cm = __ballot(ready && coop);
         stt.coops += (u32)__popcll(cm);
         while (cm) {

@@ -33,12 +33,14 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
                                                   u32* __restrict__ counters)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    zpk_decode_desc d = desc[i];
+    const bool live = i < n;
+    zpk_decode_desc d; memset(&d, 0, sizeof(d));
+    if (live) d = desc[i];
     zpk_decode_result r; r.status = R_OK; r.detail = 0; r.produced = 0; r.hash = 0;
     int list = -1;
     // lib/zpack_read.c:328-332, in this order
-    if (d.comp_size == 0) r.status = R_OK;
+    if (!live) list = -1;
+    else if (d.comp_size == 0) r.status = R_OK;
     else if (d.dst_capacity < d.uncomp_size) r.status = R_BUFFER_TOO_SMALL;
     else if (d.src_offset + d.comp_size >= src_size || d.src_offset > src_size || d.comp_size > src_size - d.src_offset)
         r.status = R_FILE_OFFSET_INVALID;
@@ -50,10 +52,18 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
     else if (d.method == ZPK_METHOD_ZSTD) list = L_ZSTD;
     else if (d.method == ZPK_METHOD_LZ4) list = L_LZ4;
     else r.status = R_COMP_METHOD_INVALID;                                     // :459
-    res[i] = r;
-    if (list >= 0) {
-        u32 pos = atomicAdd(&counters[list], 1u);
-        lists[(u64)list * list_stride + pos] = (u32)i;
+    if (live) res[i] = r;
+    // wave-aggregated append: one atomic per list per wave (a per-lane atomicAdd on three hot words cost 1.1 ms / 100k entries)
+    const int lane = lane_id();
+    #pragma unroll
+    for (int L = 0; L < N_LISTS; L++) {
+        const u64 m = __ballot(list == L);
+        if (m == 0) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&counters[L], (u32)__popcll(m));
+        base = (u32)__shfl((int)base, leader, 64);
+        if (list == L) lists[(u64)L * list_stride + base + (u32)__popcll(m & ((1ull << lane) - 1))] = (u32)i;
     }
 }
 
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
     }
 }
 
-__global__ __launch_bounds__(64) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
+__global__ __launch_bounds__(64, 6) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
                                                   const u32* __restrict__ counters, u64* __restrict__ dbg, int getenv_dbg2)
