@@ -193,7 +193,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
     bool finished = false;
     while (!finished) {
         if (wd.expired()) return D_MALFORMED;
-        const u64 tp0 = SEQ_T();
+        const u64 tp0 = SEQ_T(); (void)tp0;
         if (cpos >= C) return D_MALFORMED;          // the chain ran off the block without a final literal run
         // ---- stage [cpos, cpos + nst) ----
         const u32 nst = C - cpos < LZ4W_CHUNK + LZ4W_SLACK ? C - cpos : LZ4W_CHUNK + LZ4W_SLACK;
@@ -205,7 +205,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             else for (u32 k = i; k < nst && k < i + 16; k++) sh.stage[k] = ld8(ip + cpos + k);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        u64 ts = SEQ_T(); stt.t_stage += ts - tp0; stt.chunks++;
+        u64 ts = SEQ_T(); (void)ts; SEQ_STAT(stt.t_stage += ts - tp0; stt.chunks++);
         Lz4Bytes B; B.S = to_lds(sh.stage); B.g = ip; B.cbase = cpos; B.cend = cpos + nst;
         // ---- walks to the fixed point ----
         const u32 my_start = cpos + (u32)lane * LZ4W_SEG;
@@ -214,16 +214,16 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         u32 my_entry = my_start;
         Lz4Walk w; w.exit = my_start; w.nseq = 0; w.flags = 0; w.m0 = 0; w.m1 = 0;
         if (active) w = lz4_walk(B, my_entry, my_start, my_end, C, w);
-        { u64 t2 = SEQ_T(); stt.t_walk1 += t2 - ts; ts = t2; }
+        SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_walk1 += t2 - ts; ts = t2; });
         for (int iter = 0; iter < 66; iter++) {
-            stt.fix_iters++;
+            SEQ_STAT(stt.fix_iters++);
             u32 e = (u32)__shfl_up((int)w.exit, 1, 64);
             if (lane == 0) e = cpos;
             const bool changed = active && e != my_entry;
             if (__ballot(changed) == 0) break;
             if (changed) { my_entry = e; w = lz4_walk(B, my_entry, my_start, my_end, C, w); }
         }
-        { u64 t2 = SEQ_T(); stt.t_fix += t2 - ts; ts = t2; }
+        SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_fix += t2 - ts; ts = t2; });
         // inactive lanes forward the chain position
         if (!active) { w.exit = (u32)__shfl((int)w.exit, 63, 64); }
         const u64 lastmask = __ballot(active);
@@ -238,12 +238,11 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
         const u32 nseq = (u32)__builtin_amdgcn_readlane((int)x, 63);
         const u32 my_nseq = active ? w.nseq : 0u;
-        { u64 t2 = SEQ_T(); stt.t_emit += t2 - ts; }
-        stt.t_parse += SEQ_T() - tp0;
+        SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_emit += t2 - ts; stt.t_parse += t2 - tp0; });
         // ---- execute, 64 consecutive sequences at a time ----
         for (u32 b0 = 0; b0 < nseq; b0 += WAVE) {
             const int cnt = (int)(nseq - b0 < WAVE ? nseq - b0 : WAVE);
-            const u64 tq0 = SEQ_T();
+            const u64 tq0 = SEQ_T(); (void)tq0;
             SeqBatch q; q.lit = ip; q.ll = 0; q.ml = 0; q.off = 1;
             bool bad = false;
             // sequence number -> token position without a table: the owning segment by binary search over the
@@ -276,7 +275,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
                     bad = (t.flags & 1) || (t.ml && t.off == 0) || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
                 }
             }
-            { u64 t2 = SEQ_T(); stt.t_parse += t2 - tq0; stt.t_tok += t2 - tq0; }
+            SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_parse += t2 - tq0; stt.t_tok += t2 - tq0; });
             if (__ballot(bad) != 0) {
                 // oversize lengths mean the output slot is too small (or the input is malformed): let the sums decide
                 if (__ballot(lane < cnt && (q.ll > (u64)(oend - op) || q.ml > (u64)(oend - op))) != 0) { op_io = op; return D_DST_FULL; }
@@ -302,8 +301,6 @@ __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, Se
     const u8* iend = src + src_size;
     u8* op = dst;
     u8* oend = dst + dst_cap;
-    ByteWindow win; win.lo = src_lo; win.hi = src_hi;
-    win.load(ip, lane);
 
     for (;;) {      // skippable frames
         if (iend - ip < 4) { r.rc = D_TRUNCATED; return r; }

@@ -35,7 +35,32 @@ __device__ __forceinline__ void gcopy_upto16(u8* d, const u8* s, u32 n)
     if (n & 1) st8(d, ld8(s));
 }
 
-// the same in two halves, so that several chunks can be in flight before the first store
+// Two-halves form (loads first, stores later) for 0..32 bytes with the small-memcpy trick: any length is
+// covered by at most TWO accesses of one width, the second overlapping the first ([0,w) and [n-w,n)).
+// Scattered per-lane accesses are bound by the texture-addresser / L1 tag rate (~1 lane-address per cycle),
+// so halving the number of vector-memory instructions per copy is worth more than anything else here.
+struct Copy32 { u128 lo, hi; };           // lo = bytes [0,w) (zero-extended), hi = bytes [n-w, n)
+
+__device__ __forceinline__ Copy32 gload_upto32(const u8* s, u32 n)
+{
+    Copy32 c; c.lo.lo = c.lo.hi = c.hi.lo = c.hi.hi = 0;
+    if (n >= 16)      { c.lo = ld128(s); c.hi = ld128(s + n - 16); }
+    else if (n >= 8)  { c.lo.lo = ld64(s); c.hi.lo = ld64(s + n - 8); }
+    else if (n >= 4)  { c.lo.lo = ld32(s); c.hi.lo = ld32(s + n - 4); }
+    else if (n >= 2)  { c.lo.lo = ld16(s); c.hi.lo = ld16(s + n - 2); }
+    else if (n == 1)  { c.lo.lo = ld8(s); }
+    return c;
+}
+__device__ __forceinline__ void gstore_upto32(u8* d, const Copy32& c, u32 n)
+{
+    if (n >= 16)      { st128(d, c.lo); st128(d + n - 16, c.hi); }
+    else if (n >= 8)  { st64(d, c.lo.lo); st64(d + n - 8, c.hi.lo); }
+    else if (n >= 4)  { st32(d, (u32)c.lo.lo); st32(d + n - 4, (u32)c.hi.lo); }
+    else if (n >= 2)  { st16(d, (u16)c.lo.lo); st16(d + n - 2, (u16)c.hi.lo); }
+    else if (n == 1)  { st8(d, (u8)c.lo.lo); }
+}
+
+// legacy exact-tail helpers (cooperative paths)
 __device__ __forceinline__ u128 gload_upto16(const u8* s, u32 n)
 {
     if (n >= 16) return ld128(s);
@@ -75,11 +100,8 @@ __device__ __forceinline__ void gcopy_upto64(u8* d, const u8* s, u32 n)
 
 __device__ __forceinline__ void gcopy_upto32(u8* d, const u8* s, u32 n)
 {
-    u128 v0 = {0, 0}, v1 = {0, 0};
-    if (n > 0) v0 = gload_upto16(s, n);
-    if (n > 16) v1 = gload_upto16(s + 16, n - 16);
-    if (n > 0) gstore_upto16(d, v0, n);
-    if (n > 16) gstore_upto16(d + 16, v1, n - 16);
+    const Copy32 c = gload_upto32(s, n);
+    gstore_upto32(d, c, n);
 }
 
 __device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
@@ -89,8 +111,16 @@ __device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
 }
 
 // developer aid: cycle accounting of the executor (kept in registers; written out only when asked)
+// compiled in only with -DZPK_STATS (the counters cost ~10 registers, i.e. a wave of occupancy per SIMD)
+#ifdef ZPK_STATS
 struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; u64 t_stage, t_walk1, t_fix, t_emit, t_tok; u32 fix_iters, chunks; };
 #define SEQ_T() __builtin_amdgcn_s_memtime()
+#define SEQ_STAT(x) do { x; } while (0)
+#else
+struct SeqStats { };
+#define SEQ_T() 0ull
+#define SEQ_STAT(x) do { } while (0)
+#endif
 
 // a lane copies its own literal run / match only up to this many bytes (register budget: 2 x 16 B per kind);
 // longer ones are copied by the whole wave
@@ -108,8 +138,8 @@ struct SeqBatch {
 __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& op, u8* oend, const u8* dst_lo, int lit_rle, int lane,
                                               SeqStats& stt)
 {
-    u64 t0 = SEQ_T();
-    stt.batches++;
+    u64 t0 = SEQ_T(); (void)t0; (void)stt;
+    SEQ_STAT(stt.batches++);
     const bool act = lane < cnt;
     const u32 ll = act ? q.ll : 0u, ml = act ? q.ml : 0u;
     // ---- 1. output positions ----
@@ -166,7 +196,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
             if (inside >= 0 && !((i64)kms <= src && send <= (i64)kms + (i64)knl)) inside = -1;
             if (round == 5 || __ballot(inside >= 0) == 0) break;
             if (inside >= 0) src -= kdelta;
-            stt.redirects += (u32)__popcll(__ballot(inside >= 0));
+            SEQ_STAT(stt.redirects += (u32)__popcll(__ballot(inside >= 0)));
         }
     }
     const u8* const srcp = op + src;                               // (possibly re-pointed) source of the first need_len bytes
@@ -174,7 +204,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     const bool coop = has_match && (ml > SEQ_OWN_MAX || self_overlap);
     // matches whose whole source is older than this batch go out together with the literals
     const bool early = has_match && !coop && src + (i64)need_len <= 0;
-    { u64 t1 = SEQ_T(); stt.t_dep += t1 - t0; t0 = t1; }
+    SEQ_STAT({ u64 t1 = SEQ_T(); stt.t_dep += t1 - t0; t0 = t1; });
 
     // ---- 3. literals + early matches: every load is issued before the first store ----
     if (lit_rle >= 0) {
@@ -190,15 +220,10 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     } else {
         const bool long_lit = ll > SEQ_OWN_MAX;
         const u32 ln = long_lit ? 0u : ll, mn = early ? ml : 0u;
-        u128 a0 = {0, 0}, a1 = {0, 0}, b0 = {0, 0}, b1 = {0, 0};
-        if (ln > 0) a0 = gload_upto16(q.lit, ln);
-        if (ln > 16) a1 = gload_upto16(q.lit + 16, ln - 16);
-        if (mn > 0) b0 = gload_upto16(srcp, mn);
-        if (mn > 16) b1 = gload_upto16(srcp + 16, mn - 16);
-        if (ln > 0) gstore_upto16(o, a0, ln);
-        if (ln > 16) gstore_upto16(o + 16, a1, ln - 16);
-        if (mn > 0) gstore_upto16(ms, b0, mn);
-        if (mn > 16) gstore_upto16(ms + 16, b1, mn - 16);
+        const Copy32 ca = gload_upto32(q.lit, ln);
+        const Copy32 cb = gload_upto32(srcp, mn);
+        gstore_upto32(o, ca, ln);
+        gstore_upto32(ms, cb, mn);
         u64 lm = __ballot(long_lit);
         while (lm) {                              // long runs: whole wave, 16 B per lane
             const int k = __ffsll((long long)lm) - 1;
@@ -212,7 +237,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     wave_mem_fence();
     u64 done = ~pending | __ballot(early);                         // lanes without a match count as done
     pending &= ~done;
-    { u64 t1 = SEQ_T(); stt.t_lit += t1 - t0; t0 = t1; }
+    SEQ_STAT({ u64 t1 = SEQ_T(); stt.t_lit += t1 - t0; t0 = t1; });
 
     // ---- 4. rounds ----
     u32 guard = 0;
@@ -220,10 +245,10 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
         const bool ready = has_match && ((pending >> lane) & 1) && (need & ~done) == 0;
         const u64 rmask = __ballot(ready);
         if (rmask == 0 || ++guard > 70) return D_MALFORMED;        // cannot happen: the lowest pending lane is always ready
-        stt.rounds++;
+        SEQ_STAT(stt.rounds++);
         if (ready && !coop) gcopy_upto32(ms, srcp, ml);            // whole source final and not produced by this match
         u64 cm = __ballot(ready && coop);
-        stt.coops += (u32)__popcll(cm);
+        SEQ_STAT(stt.coops += (u32)__popcll(cm));
         while (cm) {
             const int k = __ffsll((long long)cm) - 1;
             cm &= cm - 1;
@@ -249,7 +274,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
         done |= rmask;
         pending &= ~rmask;
     }
-    { u64 t1 = SEQ_T(); stt.t_rounds += t1 - t0; }
+    SEQ_STAT({ u64 t1 = SEQ_T(); stt.t_rounds += t1 - t0; });
     op += total;
     return D_OK;
 }

@@ -166,8 +166,9 @@ __global__ __launch_bounds__(64, 6) void k_lz4_wave(const u8* __restrict__ src, 
         u8* out = uni_ptr(dst + d.dst_offset);
         Watchdog wd; wd.arm();
         SeqStats stt = {};
-        const u64 t_all = SEQ_T();
+        const u64 t_all = SEQ_T(); (void)t_all;
         DecodeOut o = lz4f_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
+#ifdef ZPK_STATS
         if (dbg && lane == 0) {
             u64* g = dbg + (u64)e * 8;
             g[0] = stt.t_parse; g[1] = stt.t_lit; g[2] = stt.t_dep; g[3] = stt.t_rounds;
@@ -175,6 +176,9 @@ __global__ __launch_bounds__(64, 6) void k_lz4_wave(const u8* __restrict__ src, 
             g[7] = ((u64)stt.fix_iters << 32) | stt.chunks;
             if (getenv_dbg2) { g[0] = stt.t_stage; g[1] = stt.t_walk1; g[2] = stt.t_fix; g[3] = stt.t_emit; g[4] = stt.t_tok; }
         }
+#else
+        (void)dbg; (void)getenv_dbg2; (void)t_all;
+#endif
         // lib/zpack_read.c:421-450
         int status = R_OK;
         if (o.rc == D_MALFORMED) status = R_DECOMPRESS_FAILED;

@@ -607,6 +607,7 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
                 q.lit = lit + lit_pos + (xl - (lane < cnt ? my_ll : 0u));
                 q.ll = my_ll; q.ml = my_ml; q.off = (u32)my_off;
                 SeqStats stt = {};
+                (void)stt;
                 const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt);
                 if (rc != D_OK) { produced = (u64)(op - dst); return rc; }
                 lit_pos += lit_total;
