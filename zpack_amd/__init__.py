@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CODEC_SO = os.path.join(HERE, "libzpk_codec.so")
+CODEC_SO = os.environ.get("ZPACK_AMD_CODEC_SO") or os.path.join(HERE, "libzpk_codec.so")     # override: A/B builds of the kernels
 ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
 
 METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2

@@ -39,6 +39,8 @@ def build_codec(force=False, verbose=False):
         return CODEC_SO
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-function", "-o", CODEC_SO, os.path.join(CSRC, "zpk_codec.hip")]
+    if os.environ.get("ZPK_STATS"):          # developer build: per-phase cycle counters in the decode kernels
+        cmd.insert(1, "-DZPK_STATS=1")
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

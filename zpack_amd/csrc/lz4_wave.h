@@ -58,8 +58,10 @@ struct DecodeOut { int rc; u64 produced; };
 // the chunk's sequences, one more walk writes each sequence's token position into a u16 record array,
 // and the chunk is then executed 64 consecutive sequences at a time: lane k re-reads token k's fields
 // from LDS and seq_exec_batch() (seq_exec.h) does the copies in HBM/L2 with in-register dependency
-// masks.  LDS per wave: 5.4 KiB chunk + 3.6 KiB records.
-#define LZ4W_SEG 84u                            // 21 dwords: odd, so 64 lanes spread over all LDS banks
+// masks.  LDS per wave: one 4.3 KiB chunk (68-byte segments measured best: 331 GiB/s vs 320 at 84, 303 at 108).
+#ifndef LZ4W_SEG
+#define LZ4W_SEG 68u                            // 17 dwords: odd, so 64 lanes spread over all LDS banks
+#endif
 #define LZ4W_CHUNK (64u * LZ4W_SEG)             // 5376
 #define LZ4W_SLACK 64u
 #define LZ4W_MAXREC (LZ4W_CHUNK / 3u + 64u)

@@ -125,6 +125,10 @@ struct SeqStats { };
 // a lane copies its own literal run / match only up to this many bytes (register budget: 2 x 16 B per kind);
 // longer ones are copied by the whole wave
 #define SEQ_OWN_MAX 32u
+// sweeps of the dependency analysis: every sweep but the last may re-point sources (chain depth halves per sweep)
+#ifndef SEQ_DEP_ROUNDS
+#define SEQ_DEP_ROUNDS 4
+#endif
 
 struct SeqBatch {
     const u8* lit;     // literal source of this lane's sequence (ignored when lit_rle)
@@ -132,36 +136,20 @@ struct SeqBatch {
     u32 off;           // match offset (>= 1 when ml != 0)
 };
 
-// Execute `cnt` sequences (lane k < cnt holds sequence k).  op = output cursor (uniform, advanced),
-// oend = end of the output slot, dst_lo = lowest address a match may read.  lit_rle >= 0: every literal
-// byte equals that value (Zstandard RLE literals).  Returns D_OK / D_MALFORMED / D_DST_FULL.
-__device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& op, u8* oend, const u8* dst_lo, int lit_rle, int lane,
-                                              SeqStats& stt)
+// In-batch dependency analysis, shared by the HBM and the LDS executor: pure cross-lane arithmetic.
+// In: this lane's match output [r_ms, r_me) and offset (positions relative to the batch start), `pending` =
+// ballot of lanes with a match.  Out: src = start of the (possibly re-pointed) source of the first need_len
+// bytes, relative to the batch start (negative = older data); returns the mask of earlier batch lanes whose
+// match output that source touches.
+__device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_me, u32 off, u32 need_len, u64 pending, int lane,
+                                                i64& src_out, SeqStats& stt)
 {
-    u64 t0 = SEQ_T(); (void)t0; (void)stt;
-    SEQ_STAT(stt.batches++);
-    const bool act = lane < cnt;
-    const u32 ll = act ? q.ll : 0u, ml = act ? q.ml : 0u;
-    // ---- 1. output positions ----
-    u32 x = ll + ml;
-    #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
-    const u64 total = (u32)__builtin_amdgcn_readlane((int)x, 63);
-    if (total > (u64)(oend - op)) return D_DST_FULL;
-    u8* const o = op + (x - (ll + ml));          // literal start of this lane's sequence
-    u8* const ms = o + ll;                        // match start
-    const bool has_match = act && ml != 0;
-    if (__ballot(has_match && (q.off == 0 || (u64)q.off > (u64)(ms - dst_lo))) != 0) return D_MALFORMED;
-    u64 pending = __ballot(has_match);
-
-    // ---- 2. in-batch dependencies: pure cross-lane arithmetic, no memory (positions relative to op) ----
-    const u32 r_ms = (u32)(ms - op), r_me = r_ms + ml;           // this lane's match output [r_ms, r_me)
-    i64 src = (i64)r_ms - (i64)q.off;                             // source start, relative to op (negative = older data)
-    const u32 need_len = ml < q.off ? ml : q.off;                 // bytes not produced by the match itself
+    (void)stt;
+    i64 src = (i64)r_ms - (i64)off;
     u64 need = 0;
     if (pending) {
         #pragma unroll 1
-        for (int round = 0; round < 6; round++) {
+        for (int round = 0; round < SEQ_DEP_ROUNDS; round++) {
             // which earlier matches of the batch does [src, src+need_len) touch?  Output ranges are sorted by
             // lane, so two binary searches over the wave (ds_bpermute, no memory) give the lane interval.
             need = 0;
@@ -194,11 +182,42 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
             const u32 dlo = (u32)__shfl((int)(u32)(u64)my_delta, probe, 64), dhi = (u32)__shfl((int)(u32)((u64)my_delta >> 32), probe, 64);
             const i64 kdelta = (i64)(((u64)dhi << 32) | dlo);
             if (inside >= 0 && !((i64)kms <= src && send <= (i64)kms + (i64)knl)) inside = -1;
-            if (round == 5 || __ballot(inside >= 0) == 0) break;
+            if (round == SEQ_DEP_ROUNDS - 1 || __ballot(inside >= 0) == 0) break;
             if (inside >= 0) src -= kdelta;
             SEQ_STAT(stt.redirects += (u32)__popcll(__ballot(inside >= 0)));
         }
     }
+    src_out = src;
+    return need;
+}
+
+// Execute `cnt` sequences (lane k < cnt holds sequence k).  op = output cursor (uniform, advanced),
+// oend = end of the output slot, dst_lo = lowest address a match may read.  lit_rle >= 0: every literal
+// byte equals that value (Zstandard RLE literals).  Returns D_OK / D_MALFORMED / D_DST_FULL.
+__device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& op, u8* oend, const u8* dst_lo, int lit_rle, int lane,
+                                              SeqStats& stt)
+{
+    u64 t0 = SEQ_T(); (void)t0; (void)stt;
+    SEQ_STAT(stt.batches++);
+    const bool act = lane < cnt;
+    const u32 ll = act ? q.ll : 0u, ml = act ? q.ml : 0u;
+    // ---- 1. output positions ----
+    u32 x = ll + ml;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
+    const u64 total = (u32)__builtin_amdgcn_readlane((int)x, 63);
+    if (total > (u64)(oend - op)) return D_DST_FULL;
+    u8* const o = op + (x - (ll + ml));          // literal start of this lane's sequence
+    u8* const ms = o + ll;                        // match start
+    const bool has_match = act && ml != 0;
+    if (__ballot(has_match && (q.off == 0 || (u64)q.off > (u64)(ms - dst_lo))) != 0) return D_MALFORMED;
+    u64 pending = __ballot(has_match);
+
+    // ---- 2. in-batch dependencies (positions relative to op) ----
+    const u32 r_ms = (u32)(ms - op), r_me = r_ms + ml;           // this lane's match output [r_ms, r_me)
+    const u32 need_len = ml < q.off ? ml : q.off;                 // bytes not produced by the match itself
+    i64 src;
+    const u64 need = seq_dependencies(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt);
     const u8* const srcp = op + src;                               // (possibly re-pointed) source of the first need_len bytes
     const bool self_overlap = ml > need_len;                       // offset < length: the match feeds itself
     const bool coop = has_match && (ml > SEQ_OWN_MAX || self_overlap);
