@@ -138,6 +138,35 @@ __device__ __forceinline__ Lz4Tok lz4_token_at(const Lz4Bytes& B, u32 p, u32 C, 
     return t;
 }
 
+// The common shapes of a sequence — at most one length-extension byte on either side, everything inside
+// the staged chunk and strictly inside the block — evaluated from LDS without loops.  Returns false when
+// the general decoder (lz4_token_at) has to look at it; a divergent slow path costs every lane of the
+// wave, so the point is to keep ordinary long matches (ml >= 19) out of it.
+template <bool FULL>
+__device__ __forceinline__ bool lz4_token_fast(const Lz4Bytes& B, u32 p, u32 C, u32 tok, Lz4Tok& t)
+{
+    const u32 lim = B.cend < C ? B.cend : C;       // bytes [p, lim) are staged and inside the block
+    u32 q = p + 1, lit = tok >> 4, ml = tok & 15;
+    bool ok = true;
+    if (lit == 15) {
+        if (q >= lim) return false;
+        const u32 b = lds_ld8(B.S + (q - B.cbase));
+        ok = b != 255; lit += b; q++;
+    }
+    t.lit_pos = q; t.lit = lit;
+    if (lit >= lim - q) return false;              // also keeps q + lit below any wrap
+    q += lit;
+    if (q + 3 > lim) return false;                 // room for the offset and one extension byte
+    if (FULL) t.off = lds_ld16(B.S + (q - B.cbase));
+    q += 2;
+    if (ml == 15) {
+        const u32 b = lds_ld8(B.S + (q - B.cbase));
+        ok = ok && b != 255; ml += b; q++;
+    }
+    t.ml = ml + 4; t.next = q; t.flags = 0;
+    return ok;
+}
+
 // Walk from `entry` while the token lies before seg_end.  The set of token positions visited (relative
 // to seg_start, < LZ4W_SEG <= 128) is kept as a bit mask; a re-walk from a new entry stops as soon as it
 // lands on a position the previous walk already visited — from there on the two chains are identical —
@@ -156,17 +185,10 @@ __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, u32 entry, u32 se
         if (r < 64) w.m0 |= 1ull << r; else w.m1 |= 1ull << (r - 64);
         // tokens of a chunk always lie inside the staged range: one ds_read, no fallback
         const u32 tok = lds_ld8(B.S + (p - B.cbase));
-        const u32 lit = tok >> 4, mlc = tok & 15;
         u32 fl = 0, nx;
-        if (lit != 15 && mlc != 15) {                   // no length extension bytes: pure arithmetic
-            const u32 q = p + 1 + lit;
-            if (q >= C) { fl = q == C ? 2u : 1u; nx = C; }
-            else if (C - q < 2) { fl = 1; nx = C; }
-            else nx = q + 2;
-        } else {
-            const Lz4Tok t = lz4_token_at(B, p, C, false);
-            fl = t.flags; nx = t.next;
-        }
+        Lz4Tok t;
+        if (lz4_token_fast<false>(B, p, C, tok, t)) nx = t.next;
+        else { t = lz4_token_at(B, p, C, false); fl = t.flags; nx = t.next; }
         w.nseq++;
         w.flags |= fl;
         p = nx;
@@ -266,13 +288,12 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
                 const u32 c0 = (u32)__popcll(om0);
                 const u32 p = rk < c0 ? ostart + nth_set_bit(om0, rk) : ostart + 64 + nth_set_bit(om1, rk - c0);
                 const u32 tok = lds_ld8(B.S + (p - B.cbase));
-                const u32 lit = tok >> 4, mlc = tok & 15;
-                const u32 qq = p + 1 + lit;
-                if (lit != 15 && mlc != 15 && qq + 2 <= B.cend && qq + 2 <= C) {     // common case: 2 LDS reads in all
-                    q.lit = ip + p + 1; q.ll = lit; q.ml = mlc + 4; q.off = lds_ld16(B.S + (qq - B.cbase));
-                    bad = q.off == 0;
+                Lz4Tok t;
+                if (lz4_token_fast<true>(B, p, C, tok, t)) {                         // common case: 2-4 LDS reads in all
+                    q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
+                    bad = q.off == 0 || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
                 } else {
-                    const Lz4Tok t = lz4_token_at(B, p, C, true);
+                    t = lz4_token_at(B, p, C, true);
                     q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
                     bad = (t.flags & 1) || (t.ml && t.off == 0) || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
                 }
