@@ -60,9 +60,10 @@ struct DecodeOut { int rc; u64 produced; };
 // from LDS and seq_exec_batch() (seq_exec.h) does the copies in HBM/L2 with in-register dependency
 // masks.  LDS per wave: one 4.3 KiB chunk (68-byte segments measured best: 331 GiB/s vs 320 at 84, 303 at 108).
 #ifndef LZ4W_SEG
-#define LZ4W_SEG 68u                            // 17 dwords: odd, so 64 lanes spread over all LDS banks
+#define LZ4W_SEG 60u                            // 15 dwords: odd, so 64 lanes spread over all LDS banks; <= 64 for the visited mask
 #endif
-#define LZ4W_CHUNK (64u * LZ4W_SEG)             // 5376
+static_assert(LZ4W_SEG <= 64u, "the visited-position mask of a segment is one 64-bit word");
+#define LZ4W_CHUNK (64u * LZ4W_SEG)
 #define LZ4W_SLACK 64u
 #define LZ4W_MAXREC (LZ4W_CHUNK / 3u + 64u)
 
@@ -168,39 +169,53 @@ __device__ __forceinline__ bool lz4_token_fast(const Lz4Bytes& B, u32 p, u32 C, 
 }
 
 // Walk from `entry` while the token lies before seg_end.  The set of token positions visited (relative
-// to seg_start, < LZ4W_SEG <= 128) is kept as a bit mask; a re-walk from a new entry stops as soon as it
+// to seg_start, < LZ4W_SEG <= 64) is kept as a bit mask; a re-walk from a new entry stops as soon as it
 // lands on a position the previous walk already visited — from there on the two chains are identical —
 // and inherits the tail.  flags (1 malformed, 2 last sequence of the block) always belong to a walk's
-// final hop, so they travel with the tail.
-struct Lz4Walk { u32 exit, nseq, flags; u64 m0, m1; };
-__device__ __forceinline__ bool mask_test(u64 m0, u64 m1, u32 r) { return ((r < 64 ? m0 >> r : m1 >> (r - 64)) & 1ull) != 0; }
+// final hop, so they travel with the tail.  The number of sequences is the mask's population count.
+//
+// INTERIOR = the block continues for at least LZ4W_SLACK staged bytes past the last token of the chunk:
+// a sequence with a short literal run (< 15) then needs no bounds check at all, and the hop is straight
+// -line code (two LDS reads, no exec-mask juggling) — the kernel is VALU/SALU-issue bound, and the hop is
+// its most executed piece.
+struct Lz4Walk { u32 exit, flags; u64 m; };
+template <bool INTERIOR>
 __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, u32 entry, u32 seg_start, u32 seg_end, u32 C, const Lz4Walk& old)
 {
-    Lz4Walk w; w.nseq = 0; w.flags = 0; w.m0 = 0; w.m1 = 0;
+    Lz4Walk w; w.flags = 0; w.m = 0;
     u32 p = entry;
     bool merged = false;
     while (p < seg_end) {
         const u32 r = p - seg_start;
-        if (mask_test(old.m0, old.m1, r)) { merged = true; break; }
-        if (r < 64) w.m0 |= 1ull << r; else w.m1 |= 1ull << (r - 64);
+        if ((old.m >> r) & 1ull) { merged = true; break; }
+        w.m |= 1ull << r;
         // tokens of a chunk always lie inside the staged range: one ds_read, no fallback
-        const u32 tok = lds_ld8(B.S + (p - B.cbase));
+        const lds_cp8 at = B.S + (p - B.cbase);
+        const u32 tok = lds_ld8(at);
         u32 fl = 0, nx;
+        bool slow;
         Lz4Tok t;
-        if (lz4_token_fast<false>(B, p, C, tok, t)) nx = t.next;
-        else { t = lz4_token_at(B, p, C, false); fl = t.flags; nx = t.next; }
-        w.nseq++;
+        if (INTERIOR) {
+            const u32 lit = tok >> 4, ext = (tok & 15) == 15 ? 1u : 0u;
+            const u32 b = lds_ld8(at + 3 + lit);            // first match-length extension byte, if there is one
+            nx = p + 3 + lit + ext;
+            slow = lit == 15 || (ext && b == 255);
+        } else {
+            slow = !lz4_token_fast<false>(B, p, C, tok, t);
+            nx = t.next;
+        }
+        if (slow) {
+            if (!INTERIOR || !lz4_token_fast<false>(B, p, C, tok, t)) t = lz4_token_at(B, p, C, false);
+            fl = t.flags; nx = t.next;
+        }
         w.flags |= fl;
         p = nx;
         if (fl) break;
     }
     w.exit = p;
     if (merged) {
-        const u32 r = p - seg_start;
-        const u64 t0 = r < 64 ? old.m0 & ~((1ull << r) - 1) : 0ull;
-        const u64 t1 = r < 64 ? old.m1 : old.m1 & ~((1ull << (r - 64)) - 1);
-        w.m0 |= t0; w.m1 |= t1;
-        w.nseq += (u32)(__popcll(t0) + __popcll(t1));
+        const u64 tail = old.m & ~((1ull << (p - seg_start)) - 1);
+        w.m |= tail;
         w.flags |= old.flags;
         w.exit = old.exit;
     }
@@ -236,8 +251,9 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         const u32 my_end = my_start + LZ4W_SEG < tok_end ? my_start + LZ4W_SEG : tok_end;
         const bool active = my_start < tok_end;
         u32 my_entry = my_start;
-        Lz4Walk w; w.exit = my_start; w.nseq = 0; w.flags = 0; w.m0 = 0; w.m1 = 0;
-        if (active) w = lz4_walk(B, my_entry, my_start, my_end, C, w);
+        const bool interior = nst == LZ4W_CHUNK + LZ4W_SLACK;      // uniform: every chunk but the last of a block
+        Lz4Walk w; w.exit = my_start; w.flags = 0; w.m = 0;
+        if (active) w = interior ? lz4_walk<true>(B, my_entry, my_start, my_end, C, w) : lz4_walk<false>(B, my_entry, my_start, my_end, C, w);
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_walk1 += t2 - ts; ts = t2; });
         for (int iter = 0; iter < 66; iter++) {
             SEQ_STAT(stt.fix_iters++);
@@ -245,7 +261,10 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             if (lane == 0) e = cpos;
             const bool changed = active && e != my_entry;
             if (__ballot(changed) == 0) break;
-            if (changed) { my_entry = e; w = lz4_walk(B, my_entry, my_start, my_end, C, w); }
+            if (changed) {
+                my_entry = e;
+                w = interior ? lz4_walk<true>(B, my_entry, my_start, my_end, C, w) : lz4_walk<false>(B, my_entry, my_start, my_end, C, w);
+            }
         }
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_fix += t2 - ts; ts = t2; });
         // inactive lanes forward the chain position
@@ -257,11 +276,11 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         if (fl) return D_MALFORMED;
         if (__ballot(active && (w.flags & 2)) != 0) finished = true;          // the block's last sequence is in this chunk
         // ---- sequence numbers + token records ----
-        u32 x = active ? w.nseq : 0u;
+        u32 x = active ? (u32)__popcll(w.m) : 0u;
         #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
         const u32 nseq = (u32)__builtin_amdgcn_readlane((int)x, 63);
-        const u32 my_nseq = active ? w.nseq : 0u;
+        const u32 my_nseq = active ? (u32)__popcll(w.m) : 0u;
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_emit += t2 - ts; stt.t_parse += t2 - tp0; });
         // ---- execute, 64 consecutive sequences at a time ----
         for (u32 b0 = 0; b0 < nseq; b0 += WAVE) {
@@ -281,15 +300,19 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             if (own > 63) own = 63;
             const u32 ox = (u32)__shfl((int)x, own, 64), on = (u32)__shfl((int)my_nseq, own, 64);
             const u32 ostart = (u32)__shfl((int)my_start, own, 64);
-            const u64 om0 = ((u64)(u32)__shfl((int)(u32)(w.m0 >> 32), own, 64) << 32) | (u32)__shfl((int)(u32)w.m0, own, 64);
-            const u64 om1 = ((u64)(u32)__shfl((int)(u32)(w.m1 >> 32), own, 64) << 32) | (u32)__shfl((int)(u32)w.m1, own, 64);
+            const u64 om = ((u64)(u32)__shfl((int)(u32)(w.m >> 32), own, 64) << 32) | (u32)__shfl((int)(u32)w.m, own, 64);
             if (lane < cnt) {
-                u32 rk = sq - (ox - on);
-                const u32 c0 = (u32)__popcll(om0);
-                const u32 p = rk < c0 ? ostart + nth_set_bit(om0, rk) : ostart + 64 + nth_set_bit(om1, rk - c0);
-                const u32 tok = lds_ld8(B.S + (p - B.cbase));
+                const u32 p = ostart + nth_set_bit(om, sq - (ox - on));
+                const lds_cp8 at = B.S + (p - B.cbase);
+                const u32 tok = lds_ld8(at);
+                const u32 lit = tok >> 4, mlc = tok & 15;
+                u32 o16 = 0, eb = 255;
+                if (interior) { o16 = lds_ld16(at + 1 + lit); eb = lds_ld8(at + 3 + lit); }   // unconditional: in range, maybe unused
                 Lz4Tok t;
-                if (lz4_token_fast<true>(B, p, C, tok, t)) {                         // common case: 2-4 LDS reads in all
+                if (interior && lit != 15 && !(mlc == 15 && eb == 255)) {            // straight-line common case
+                    q.lit = ip + p + 1; q.ll = lit; q.ml = mlc + 4 + (mlc == 15 ? eb : 0u); q.off = o16;
+                    bad = o16 == 0;
+                } else if (lz4_token_fast<true>(B, p, C, tok, t)) {                         // common case: 2-4 LDS reads in all
                     q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
                     bad = q.off == 0 || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
                 } else {
