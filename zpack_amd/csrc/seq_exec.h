@@ -125,7 +125,7 @@ struct SeqStats { };
 // a lane copies its own literal run / match only up to this many bytes (register budget: 2 x 16 B per kind);
 // longer ones are copied by the whole wave
 #define SEQ_OWN_MAX 32u
-// sweeps of the dependency analysis: every sweep but the last may re-point sources (chain depth halves per sweep)
+// pointer-jumping rounds of the dependency analysis (chain depth halves per round)
 #ifndef SEQ_DEP_ROUNDS
 #define SEQ_DEP_ROUNDS 4
 #endif
@@ -136,55 +136,61 @@ struct SeqBatch {
     u32 off;           // match offset (>= 1 when ml != 0)
 };
 
-// In-batch dependency analysis, shared by the HBM and the LDS executor: pure cross-lane arithmetic.
+// In-batch dependency analysis: pure cross-lane arithmetic (ds_bpermute + ALU, no memory).
 // In: this lane's match output [r_ms, r_me) and offset (positions relative to the batch start), `pending` =
 // ballot of lanes with a match.  Out: src = start of the (possibly re-pointed) source of the first need_len
-// bytes, relative to the batch start (negative = older data); returns the mask of earlier batch lanes whose
-// match output that source touches.
+// bytes, relative to the batch start (negative = older data); returns a mask of earlier batch lanes whose
+// match output must be final before that source may be read.
+//
+// One search gives, per lane, the exact set of earlier matches its source touches.  A source that sits
+// entirely inside the externally-sourced part of ONE earlier match k ("inside" = k) can be read from k's own
+// source instead: window[x] == window[x - delta_k] holds there.  Such lanes then form a forest, and pointer
+// jumping over it needs no further search: after a jump, lane j's source is a sub-range of k's source, so
+// k's dependency set is a valid (superset) set for j, and if k's source sits inside m's, so does j's.
+// (delta, need, inside) of k are read before k itself jumps in the same round, which keeps the triple
+// consistent; the depth of every chain halves per round.
 __device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_me, u32 off, u32 need_len, u64 pending, int lane,
                                                 i64& src_out, SeqStats& stt)
 {
     (void)stt;
     i64 src = (i64)r_ms - (i64)off;
     u64 need = 0;
-    if (pending) {
-        #pragma unroll 1
-        for (int round = 0; round < SEQ_DEP_ROUNDS; round++) {
-            // which earlier matches of the batch does [src, src+need_len) touch?  Output ranges are sorted by
-            // lane, so two binary searches over the wave (ds_bpermute, no memory) give the lane interval.
-            need = 0;
-            int inside = -1;                                       // lane whose match holds the whole source
-            const i64 send = src + (i64)need_len;
-            const bool reads_batch = has_match && send > 0;
-            if (__ballot(reads_batch) == 0) break;                 // nobody reads batch output
-            int klo = 0, khi = 0;                                  // klo = first lane with r_me > src; khi = first lane with r_ms >= send
-            #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const u32 a = (u32)__shfl((int)r_me, klo + step - 1, 64);
-                const u32 b = (u32)__shfl((int)r_ms, khi + step - 1, 64);
-                if ((i64)a <= src) klo += step;
-                if ((i64)b < send) khi += step;
-            }
-            if (reads_batch && klo < khi) {
-                if (khi > lane) khi = lane;
-                const u64 span = (khi >= 64 ? ~0ull : ((1ull << khi) - 1)) & ~((1ull << klo) - 1);
-                need = span & pending;                             // only lanes that actually have a match
-                if (need && (need & (need - 1)) == 0) inside = __ffsll((long long)need) - 1;   // exactly one candidate
-            }
-            // Re-point a source that sits entirely inside the externally-sourced part of ONE earlier match at
-            // that match's own (possibly already re-pointed) source: window[x] == window[x - delta_k] holds
-            // there, and composing deltas halves chain depth per round.  The last sweep never redirects, so
-            // `need` always describes the final source.  Cross-lane reads stay outside divergent control flow.
+    const i64 send0 = src + (i64)need_len;
+    const bool reads_batch = has_match && send0 > 0;
+    if (pending && __ballot(reads_batch) != 0) {
+        // which earlier matches of the batch does [src, send) touch?  Output ranges are sorted by lane, so two
+        // binary searches over the wave give the lane interval.
+        int inside = -1;                                       // lane whose match holds the whole source
+        int klo = 0, khi = 0;                                  // klo = first lane with r_me > src; khi = first lane with r_ms >= send
+        #pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const u32 a = (u32)__shfl((int)r_me, klo + step - 1, 64);
+            const u32 b = (u32)__shfl((int)r_ms, khi + step - 1, 64);
+            if ((i64)a <= src) klo += step;
+            if ((i64)b < send0) khi += step;
+        }
+        if (reads_batch && klo < khi) {
+            if (khi > lane) khi = lane;
+            const u64 span = (khi >= 64 ? ~0ull : ((1ull << khi) - 1)) & ~((1ull << klo) - 1);
+            need = span & pending;                             // only lanes that actually have a match
+            if (need && (need & (need - 1)) == 0) inside = __ffsll((long long)need) - 1;   // exactly one candidate
+        }
+        {   // containment in the candidate's externally-sourced part; cross-lane reads stay outside divergent control flow
             const int probe = inside < 0 ? lane : inside;
             const u32 kms = (u32)__shfl((int)r_ms, probe, 64);
             const u32 knl = (u32)__shfl((int)need_len, probe, 64);
+            if (inside >= 0 && !((i64)kms <= src && send0 <= (i64)kms + (i64)knl)) inside = -1;
+        }
+        #pragma unroll 1
+        for (int round = 0; round < SEQ_DEP_ROUNDS; round++) {
+            if (__ballot(inside >= 0) == 0) break;
+            SEQ_STAT(stt.redirects += (u32)__popcll(__ballot(inside >= 0)));
+            const int probe = inside < 0 ? lane : inside;
             const i64 my_delta = (i64)r_ms - src;
             const u32 dlo = (u32)__shfl((int)(u32)(u64)my_delta, probe, 64), dhi = (u32)__shfl((int)(u32)((u64)my_delta >> 32), probe, 64);
-            const i64 kdelta = (i64)(((u64)dhi << 32) | dlo);
-            if (inside >= 0 && !((i64)kms <= src && send <= (i64)kms + (i64)knl)) inside = -1;
-            if (round == SEQ_DEP_ROUNDS - 1 || __ballot(inside >= 0) == 0) break;
-            if (inside >= 0) src -= kdelta;
-            SEQ_STAT(stt.redirects += (u32)__popcll(__ballot(inside >= 0)));
+            const u32 nlo = (u32)__shfl((int)(u32)need, probe, 64), nhi = (u32)__shfl((int)(u32)(need >> 32), probe, 64);
+            const int kin = __shfl(inside, probe, 64);
+            if (inside >= 0) { src -= (i64)(((u64)dhi << 32) | dlo); need = ((u64)nhi << 32) | nlo; inside = kin; }
         }
     }
     src_out = src;
