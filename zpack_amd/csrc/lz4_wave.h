@@ -68,7 +68,7 @@ static_assert(LZ4W_SEG <= 64u, "the visited-position mask of a segment is one 64
 #define LZ4W_MAXREC (LZ4W_CHUNK / 3u + 64u)
 
 struct alignas(16) Lz4WaveShared {
-    u8  stage[LZ4W_CHUNK + LZ4W_SLACK];          // 5.4 KiB per wave: the only LDS this kernel uses
+    u8  stage[LZ4W_CHUNK + LZ4W_SLACK + 16];     // + 16: literal runs are read 16 bytes at a time          // 5.4 KiB per wave: the only LDS this kernel uses
 };
 
 // r-th (0-based) set bit of w; r < popcount(w)
@@ -286,7 +286,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         for (u32 b0 = 0; b0 < nseq; b0 += WAVE) {
             const int cnt = (int)(nseq - b0 < WAVE ? nseq - b0 : WAVE);
             const u64 tq0 = SEQ_T(); (void)tq0;
-            SeqBatch q; q.lit = ip; q.ll = 0; q.ml = 0; q.off = 1;
+            SeqBatch q; q.lit = ip; q.lit_lds = SEQ_NO_LDS; q.ll = 0; q.ml = 0; q.off = 1;
             bool bad = false;
             // sequence number -> token position without a table: the owning segment by binary search over the
             // wave's prefix sums, then the rank-th set bit of that lane's visited mask (all ds_bpermute + ALU)
@@ -320,6 +320,8 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
                     q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
                     bad = (t.flags & 1) || (t.ml && t.off == 0) || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
                 }
+                const u32 lp = (u32)(q.lit - ip);                                      // literals that sit in the staged chunk
+                if (q.ll <= SEQ_OWN_MAX && lp + q.ll <= B.cend) q.lit_lds = lp - B.cbase;
             }
             SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_parse += t2 - tq0; stt.t_tok += t2 - tq0; });
             if (__ballot(bad) != 0) {
@@ -327,7 +329,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
                 if (__ballot(lane < cnt && (q.ll > (u64)(oend - op) || q.ml > (u64)(oend - op))) != 0) { op_io = op; return D_DST_FULL; }
                 return D_MALFORMED;
             }
-            const int rc = seq_exec_batch(q, cnt, op, oend, dst_lo, -1, lane, stt);
+            const int rc = seq_exec_batch(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S);
             if (rc != D_OK) { op_io = op; return rc; }
         }
         if (!finished && chain_exit <= cpos) return D_MALFORMED;               // no progress: cannot happen

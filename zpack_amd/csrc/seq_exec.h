@@ -60,6 +60,37 @@ __device__ __forceinline__ void gstore_upto32(u8* d, const Copy32& c, u32 n)
     else if (n == 1)  { st8(d, (u8)c.lo.lo); }
 }
 
+// Wide form: ONE 16-byte load covers every length up to 16 when the 16 bytes are readable (`wide`: the
+// caller knows the buffer extends that far; what lies past n is never stored), two overlapping ones cover
+// 17..32.  The store side then needs bytes [0,n) of c.lo exactly: gstore_wide32 splits n < 16 by its bits
+// (at most 4 stores per wave instead of 7 for the two-overlap form, and no second load).
+__device__ __forceinline__ Copy32 gload_wide32(const u8* s, u32 n, bool wide)
+{
+    Copy32 c; c.lo.lo = c.lo.hi = c.hi.lo = c.hi.hi = 0;
+    if (n > 16)      { c.lo = ld128(s); c.hi = ld128(s + n - 16); }
+    else if (n == 0) { }
+    else if (wide)   { c.lo = ld128(s); }
+    else {
+        u64 lo = 0, t = 0; u32 sh = 0; const u8* p = s;
+        if (n & 8) { lo = ld64(p); p += 8; }
+        if (n & 4) { t = (u64)ld32(p); sh = 32; p += 4; }
+        if (n & 2) { t |= (u64)ld16(p) << sh; sh += 16; p += 2; }
+        if (n & 1) { t |= (u64)ld8(p) << sh; }
+        if (n & 8) { c.lo.lo = lo; c.lo.hi = t; } else c.lo.lo = t;
+        if (n == 16) c.lo = ld128(s);
+    }
+    return c;
+}
+__device__ __forceinline__ void gstore_wide32(u8* d, const Copy32& c, u32 n)
+{
+    if (n >= 16) { st128(d, c.lo); if (n > 16) st128(d + n - 16, c.hi); return; }
+    u64 t = c.lo.lo;
+    if (n & 8) { st64(d, t); d += 8; t = c.lo.hi; }
+    if (n & 4) { st32(d, (u32)t); d += 4; t >>= 32; }
+    if (n & 2) { st16(d, (u16)t); d += 2; t >>= 16; }
+    if (n & 1) st8(d, (u8)t);
+}
+
 // legacy exact-tail helpers (cooperative paths)
 __device__ __forceinline__ u128 gload_upto16(const u8* s, u32 n)
 {
@@ -130,8 +161,10 @@ struct SeqStats { };
 #define SEQ_DEP_ROUNDS 4
 #endif
 
+#define SEQ_NO_LDS 0xFFFFFFFFu
 struct SeqBatch {
     const u8* lit;     // literal source of this lane's sequence (ignored when lit_rle)
+    u32 lit_lds;       // byte offset of the same literals in the caller's LDS staging buffer, or SEQ_NO_LDS
     u32 ll, ml;        // literal length, match length (0 = no match)
     u32 off;           // match offset (>= 1 when ml != 0)
 };
@@ -200,8 +233,9 @@ __device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_
 // Execute `cnt` sequences (lane k < cnt holds sequence k).  op = output cursor (uniform, advanced),
 // oend = end of the output slot, dst_lo = lowest address a match may read.  lit_rle >= 0: every literal
 // byte equals that value (Zstandard RLE literals).  Returns D_OK / D_MALFORMED / D_DST_FULL.
+// lit_stage: LDS buffer q.lit_lds indexes (16 readable bytes past every literal run it is used for), or null.
 __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& op, u8* oend, const u8* dst_lo, int lit_rle, int lane,
-                                              SeqStats& stt)
+                                              SeqStats& stt, lds_cp8 lit_stage = nullptr)
 {
     u64 t0 = SEQ_T(); (void)t0; (void)stt;
     SEQ_STAT(stt.batches++);
@@ -241,14 +275,21 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
                 for (u32 c = lane; c < n; c += WAVE) st8(p + c, (u8)lit_rle);
             }
         }
-        if (early) gcopy_upto32(ms, srcp, ml);
+        if (early) { const Copy32 cb = gload_wide32(srcp, ml, srcp + 16 <= oend); gstore_wide32(ms, cb, ml); }
     } else {
         const bool long_lit = ll > SEQ_OWN_MAX;
         const u32 ln = long_lit ? 0u : ll, mn = early ? ml : 0u;
-        const Copy32 ca = gload_upto32(q.lit, ln);
-        const Copy32 cb = gload_upto32(srcp, mn);
-        gstore_upto32(o, ca, ln);
-        gstore_upto32(ms, cb, mn);
+        // literals straight from the staged input when the caller has it in LDS (no vector-memory load at all);
+        // match sources may be over-read up to the end of this entry's own output slot
+        Copy32 ca;
+        const bool from_lds = q.lit_lds != SEQ_NO_LDS;
+        if (from_lds) {
+            ca.lo.lo = ca.lo.hi = ca.hi.lo = ca.hi.hi = 0;
+            if (ln) { ca.lo = lds_ld128(lit_stage + q.lit_lds); if (ln > 16) ca.hi = lds_ld128(lit_stage + q.lit_lds + (ln - 16)); }
+        } else ca = gload_wide32(q.lit, ln, false);
+        const Copy32 cb = gload_wide32(srcp, mn, srcp + 16 <= oend);
+        gstore_wide32(o, ca, ln);
+        gstore_wide32(ms, cb, mn);
         u64 lm = __ballot(long_lit);
         while (lm) {                              // long runs: whole wave, 16 B per lane
             const int k = __ffsll((long long)lm) - 1;
@@ -271,7 +312,10 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
         const u64 rmask = __ballot(ready);
         if (rmask == 0 || ++guard > 70) return D_MALFORMED;        // cannot happen: the lowest pending lane is always ready
         SEQ_STAT(stt.rounds++);
-        if (ready && !coop) gcopy_upto32(ms, srcp, ml);            // whole source final and not produced by this match
+        if (ready && !coop) {                                      // whole source final and not produced by this match
+            const Copy32 cb = gload_wide32(srcp, ml, srcp + 16 <= oend);
+            gstore_wide32(ms, cb, ml);
+        }
         u64 cm = __ballot(ready && coop);
         SEQ_STAT(stt.coops += (u32)__popcll(cm));
         while (cm) {

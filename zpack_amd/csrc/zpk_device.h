@@ -93,6 +93,12 @@ typedef const ZPK_LDS u8* lds_cp8;
 __device__ __forceinline__ lds_cp8 to_lds(const u8* p) { return (lds_cp8)p; }
 __device__ __forceinline__ u32 lds_ld8(lds_cp8 p)  { return (u32)*p; }
 __device__ __forceinline__ u32 lds_ld16(lds_cp8 p) { return (u32)((const ZPK_LDS pk16*)p)->v; }
+__device__ __forceinline__ u128 lds_ld128(lds_cp8 p)      // one ds_read_b128 at any byte offset
+{
+    const v4u32 x = *(const ZPK_LDS v4u32_u*)p;
+    u128 r; r.lo = ((u64)x.y << 32) | x.x; r.hi = ((u64)x.w << 32) | x.z;
+    return r;
+}
 
 // uniform byte / halfword / word reads: one lane-0 style load broadcast through an SGPR
 __device__ __forceinline__ u32 uld8(const u8* p) { return uni((u32)ld8(p)); }

@@ -605,7 +605,7 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
                 if (__ballot(lane < cnt && (my_off == 0 || my_off > 0xFFFFFFFFull)) != 0) return D_MALFORMED;
                 SeqBatch q;
                 q.lit = lit + lit_pos + (xl - (lane < cnt ? my_ll : 0u));
-                q.ll = my_ll; q.ml = my_ml; q.off = (u32)my_off;
+                q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = (u32)my_off;
                 SeqStats stt = {};
                 (void)stt;
                 const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt);
