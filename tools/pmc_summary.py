@@ -1,0 +1,45 @@
+"""Summarise tools/pmc.sh output: per kernel, the mean of every counter over its dispatches.
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (MI355X_MICROARCH.md, HBM section); they are
+converted to bytes here.  Usage: python tools/pmc_summary.py <dir> [--json out.json]
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def summarise(d):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                if not name.startswith("k_") and "zpk" not in name:
+                    continue
+                acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    out = {}
+    for k, cs in acc.items():
+        out[k] = {}
+        for c, v in cs.items():
+            # the first dispatches are warm-up launches; all launches of a kernel do the same work here
+            m = sum(v) / len(v)
+            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                m *= 1024.0
+                c += "_bytes"
+            out[k][c] = m
+        out[k]["dispatches"] = max(len(v) for v in cs.values())
+    return out
+
+
+if __name__ == "__main__":
+    s = summarise(sys.argv[1])
+    if "--json" in sys.argv:
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
+            json.dump(s, fh, indent=1, sort_keys=True)
+    for k in sorted(s):
+        print(k)
+        for c in sorted(s[k]):
+            print("    %-32s %.6g" % (c, s[k][c]))

@@ -65,23 +65,15 @@ struct DecodeOut { int rc; u64 produced; };
 static_assert(LZ4W_SEG <= 64u, "the visited-position mask of a segment is one 64-bit word");
 #define LZ4W_CHUNK (64u * LZ4W_SEG)
 #define LZ4W_SLACK 64u
-#define LZ4W_MAXREC (LZ4W_CHUNK / 3u + 64u)
 
+#ifndef LZ4W_NREC
+#define LZ4W_NREC 576u                           // token-position list: 9 batches of 64 sequences.  Measured: total LDS <= 5 KiB
+                                                 // per wave keeps 28 waves per CU (482 GiB/s); 5.5 KiB loses waves (451 GiB/s)
+#endif
 struct alignas(16) Lz4WaveShared {
-    u8  stage[LZ4W_CHUNK + LZ4W_SLACK + 16];     // + 16: literal runs are read 16 bytes at a time          // 5.4 KiB per wave: the only LDS this kernel uses
+    u8  stage[LZ4W_CHUNK + LZ4W_SLACK + 16];     // + 16: literal runs are read 16 bytes at a time
+    u16 rec[LZ4W_NREC];                          // chunk-relative token position of sequence (b0 window + i)
 };
-
-// r-th (0-based) set bit of w; r < popcount(w)
-__device__ __forceinline__ u32 nth_set_bit(u64 w, u32 r)
-{
-    u32 pos = 0;
-    #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
-        const u32 c = (u32)__popcll((w >> pos) & ((1ull << sh) - 1));
-        if (r >= c) { r -= c; pos += (u32)sh; }
-    }
-    return pos;
-}
 
 // byte `pos` of the block: from the staged chunk when it is there, else from memory (only a sequence
 // whose literal run crosses the end of the chunk gets there)
@@ -276,33 +268,36 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         if (fl) return D_MALFORMED;
         if (__ballot(active && (w.flags & 2)) != 0) finished = true;          // the block's last sequence is in this chunk
         // ---- sequence numbers + token records ----
-        u32 x = active ? (u32)__popcll(w.m) : 0u;
-        #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
-        const u32 nseq = (u32)__builtin_amdgcn_readlane((int)x, 63);
         const u32 my_nseq = active ? (u32)__popcll(w.m) : 0u;
+        const u32 x = wave_scan_add(my_nseq);
+        const u32 nseq = (u32)__builtin_amdgcn_readlane((int)x, 63);
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_emit += t2 - ts; stt.t_parse += t2 - tp0; });
         // ---- execute, 64 consecutive sequences at a time ----
+        // Every segment lists the token positions of its sequences (chunk-relative, 16 bit) at their sequence
+        // numbers in LDS — a short loop over the set bits of its mask — so that a batch lane finds its token with
+        // one ds_read.  The list holds LZ4W_NREC entries; a chunk with more sequences is listed in windows.
+        ZPK_LDS u16* const rec = (ZPK_LDS u16*)sh.rec;
         for (u32 b0 = 0; b0 < nseq; b0 += WAVE) {
+            if (b0 % LZ4W_NREC == 0) {
+                wave_mem_fence();
+                u64 m = w.m;
+                u32 k = x - my_nseq;                                           // number of this lane's first sequence
+                const u32 rel = my_start - cpos;
+                while (m) {
+                    const u32 b = (u32)__ffsll((long long)m) - 1u;
+                    m &= m - 1;
+                    if (k - b0 < LZ4W_NREC) rec[k - b0] = (u16)(rel + b);      // k < b0 wraps to a huge value
+                    k++;
+                }
+                wave_mem_fence();                                              // LDS is in order within a wave
+            }
             const int cnt = (int)(nseq - b0 < WAVE ? nseq - b0 : WAVE);
             const u64 tq0 = SEQ_T(); (void)tq0;
             SeqBatch q; q.lit = ip; q.lit_lds = SEQ_NO_LDS; q.ll = 0; q.ml = 0; q.off = 1;
             bool bad = false;
-            // sequence number -> token position without a table: the owning segment by binary search over the
-            // wave's prefix sums, then the rank-th set bit of that lane's visited mask (all ds_bpermute + ALU)
             const u32 sq = b0 + (u32)lane;
-            int own = 0;
-            #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const u32 v = (u32)__shfl((int)x, own + step - 1, 64);
-                if (v <= sq) own += step;
-            }
-            if (own > 63) own = 63;
-            const u32 ox = (u32)__shfl((int)x, own, 64), on = (u32)__shfl((int)my_nseq, own, 64);
-            const u32 ostart = (u32)__shfl((int)my_start, own, 64);
-            const u64 om = ((u64)(u32)__shfl((int)(u32)(w.m >> 32), own, 64) << 32) | (u32)__shfl((int)(u32)w.m, own, 64);
             if (lane < cnt) {
-                const u32 p = ostart + nth_set_bit(om, sq - (ox - on));
+                const u32 p = cpos + (u32)rec[sq % LZ4W_NREC];
                 const lds_cp8 at = B.S + (p - B.cbase);
                 const u32 tok = lds_ld8(at);
                 const u32 lit = tok >> 4, mlc = tok & 15;

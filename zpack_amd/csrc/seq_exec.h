@@ -242,9 +242,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     const bool act = lane < cnt;
     const u32 ll = act ? q.ll : 0u, ml = act ? q.ml : 0u;
     // ---- 1. output positions ----
-    u32 x = ll + ml;
-    #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
+    const u32 x = wave_scan_add(ll + ml);
     const u64 total = (u32)__builtin_amdgcn_readlane((int)x, 63);
     if (total > (u64)(oend - op)) return D_DST_FULL;
     u8* const o = op + (x - (ll + ml));          // literal start of this lane's sequence

@@ -112,6 +112,25 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int mask)
     return ((u64)hi << 32) | lo;
 }
 
+// inclusive prefix sum over the wave with DPP (row shifts + the gfx9 row broadcasts): six v_add_u32_dpp,
+// no LDS traffic — a ds_bpermute ladder costs ~5x the instructions
+__device__ __forceinline__ u32 wave_scan_add(u32 v)
+{
+#ifdef ZPK_NO_DPP
+    const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)v, d, 64); if (lane_ >= d) v += y; }
+    return v;
+#endif
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // lanes of one wave exchange data through global memory / LDS: the hardware keeps a wave's vector
 // memory operations in order, so a wavefront-scope fence (a compiler barrier, no s_waitcnt) suffices.
 __device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
