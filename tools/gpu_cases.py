@@ -90,7 +90,7 @@ def run_case(name):
                 print("    parse split (median cycles/entry): stage %.0f walk1 %.0f fix %.0f emit+scan %.0f token-fetch %.0f | fix iters %.0f chunks %.0f"
                       % (m(0), m(1), m(2), m(3), m(4), np.median(raw[:, 7] >> 32), np.median(raw[:, 7] & 0xffffffff)), flush=True)
             else:
-                print("    wave kernel cycles (median/entry): parse %.0f lit %.0f dep %.0f rounds %.0f total %.0f | batches %.0f rounds %.0f coops %.0f redirects %.0f"
+                print("    wave kernel cycles (median/entry): parse %.0f lit %.0f dep %.0f rounds %.0f total %.0f | batches %.0f rounds %.0f coops %.0f lds-assembled %.0f"
                       % (m(0), m(1), m(2), m(3), m(6), np.median(raw[:, 4] >> 32), np.median(raw[:, 4] & 0xffffffff),
                          np.median(raw[:, 5] >> 32), np.median(raw[:, 5] & 0xffffffff)), flush=True)
             t = raw.astype(np.float64)

@@ -296,8 +296,10 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             SeqBatch q; q.lit = ip; q.lit_lds = SEQ_NO_LDS; q.ll = 0; q.ml = 0; q.off = 1;
             bool bad = false;
             const u32 sq = b0 + (u32)lane;
+            u32 tok_pos = cpos;
             if (lane < cnt) {
                 const u32 p = cpos + (u32)rec[sq % LZ4W_NREC];
+                tok_pos = p;
                 const lds_cp8 at = B.S + (p - B.cbase);
                 const u32 tok = lds_ld8(at);
                 const u32 lit = tok >> 4, mlc = tok & 15;
@@ -324,7 +326,11 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
                 if (__ballot(lane < cnt && (q.ll > (u64)(oend - op) || q.ml > (u64)(oend - op))) != 0) { op_io = op; return D_DST_FULL; }
                 return D_MALFORMED;
             }
-            const int rc = seq_exec_batch(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S);
+            // Input this chunk has already consumed (everything before the batch's first token) is dead: the
+            // executor assembles the batch there.  The first batch or two of a chunk find too little room and
+            // take the direct path.
+            const u32 dead = (u32)__builtin_amdgcn_readfirstlane((int)tok_pos) - cpos;
+            const int rc = seq_exec_batch(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
             if (rc != D_OK) { op_io = op; return rc; }
         }
         if (!finished && chain_exit <= cpos) return D_MALFORMED;               // no progress: cannot happen

@@ -91,6 +91,17 @@ __device__ __forceinline__ void gstore_wide32(u8* d, const Copy32& c, u32 n)
     if (n & 1) st8(d, (u8)t);
 }
 
+// the same split into an LDS buffer (batch assembly, see seq_exec_batch)
+__device__ __forceinline__ void lds_store_wide32(lds_p8 d, const Copy32& c, u32 n)
+{
+    if (n >= 16) { lds_st128(d, c.lo); if (n > 16) lds_st128(d + n - 16, c.hi); return; }
+    u64 t = c.lo.lo;
+    if (n & 8) { lds_st64(d, t); d += 8; t = c.lo.hi; }
+    if (n & 4) { lds_st32(d, (u32)t); d += 4; t >>= 32; }
+    if (n & 2) { lds_st16(d, (u16)t); d += 2; t >>= 16; }
+    if (n & 1) lds_st8(d, (u8)t);
+}
+
 // legacy exact-tail helpers (cooperative paths)
 __device__ __forceinline__ u128 gload_upto16(const u8* s, u32 n)
 {
@@ -144,7 +155,7 @@ __device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
 // developer aid: cycle accounting of the executor (kept in registers; written out only when asked)
 // compiled in only with -DZPK_STATS (the counters cost ~10 registers, i.e. a wave of occupancy per SIMD)
 #ifdef ZPK_STATS
-struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; u64 t_stage, t_walk1, t_fix, t_emit, t_tok; u32 fix_iters, chunks; };
+struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; u64 t_stage, t_walk1, t_fix, t_emit, t_tok; u32 fix_iters, chunks, asm_batches; };
 #define SEQ_T() __builtin_amdgcn_s_memtime()
 #define SEQ_STAT(x) do { x; } while (0)
 #else
@@ -162,6 +173,10 @@ struct SeqStats { };
 #endif
 
 #define SEQ_NO_LDS 0xFFFFFFFFu
+// Batch assembly buffer (optional, LDS, per wave): SEQ_ASM_PRE bytes of history, the batch output, 16 bytes of
+// read slack.
+#define SEQ_ASM_PRE 32u
+#define SEQ_ASM_SLACK 16u
 struct SeqBatch {
     const u8* lit;     // literal source of this lane's sequence (ignored when lit_rle)
     u32 lit_lds;       // byte offset of the same literals in the caller's LDS staging buffer, or SEQ_NO_LDS
@@ -234,8 +249,14 @@ __device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_
 // oend = end of the output slot, dst_lo = lowest address a match may read.  lit_rle >= 0: every literal
 // byte equals that value (Zstandard RLE literals).  Returns D_OK / D_MALFORMED / D_DST_FULL.
 // lit_stage: LDS buffer q.lit_lds indexes (16 readable bytes past every literal run it is used for), or null.
+// asm_buf/asm_cap: per-wave LDS scratch of asm_cap bytes (0 = none) that does not overlap this batch's
+// literals.  A batch whose output fits (SEQ_ASM_PRE + total + SEQ_ASM_SLACK <= asm_cap) and that has no long or
+// self-overlapping piece is ASSEMBLED IN LDS: literals and matches are written there, in-batch sources are
+// read back from there at LDS latency instead of a store->load round trip through L2, and the finished batch
+// goes to memory as one contiguous 16-bytes-per-lane stream — one or two full store instructions instead of
+// ~17 partially filled ones.
 __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& op, u8* oend, const u8* dst_lo, int lit_rle, int lane,
-                                              SeqStats& stt, lds_cp8 lit_stage = nullptr)
+                                              SeqStats& stt, lds_cp8 lit_stage = nullptr, lds_p8 asm_buf = nullptr, u32 asm_cap = 0)
 {
     u64 t0 = SEQ_T(); (void)t0; (void)stt;
     SEQ_STAT(stt.batches++);
@@ -262,6 +283,56 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     // matches whose whole source is older than this batch go out together with the literals
     const bool early = has_match && !coop && src + (i64)need_len <= 0;
     SEQ_STAT({ u64 t1 = SEQ_T(); stt.t_dep += t1 - t0; t0 = t1; });
+
+    // ---- 3a. assembly in LDS ----
+    if (lit_rle < 0 && total + (SEQ_ASM_PRE + SEQ_ASM_SLACK) <= (u64)asm_cap) {
+        const bool straddle = has_match && !early && src < 0;                       // source begins before the batch, ends inside
+        const u64 sm = __ballot(straddle);
+        if (__ballot(coop || ll > SEQ_OWN_MAX) == 0 && (sm == 0 || (u64)(op - dst_lo) >= SEQ_ASM_PRE)) {
+            SEQ_STAT(stt.asm_batches++);
+            const lds_p8 ob = asm_buf + SEQ_ASM_PRE;                                // batch position 0
+            if (sm != 0 && lane < 2) lds_st128(asm_buf + 16 * lane, ld128(op - SEQ_ASM_PRE + 16 * lane));
+            Copy32 ca;
+            if (q.lit_lds != SEQ_NO_LDS) {
+                ca.lo.lo = ca.lo.hi = ca.hi.lo = ca.hi.hi = 0;
+                if (ll) { ca.lo = lds_ld128(lit_stage + q.lit_lds); if (ll > 16) ca.hi = lds_ld128(lit_stage + q.lit_lds + (ll - 16)); }
+            } else ca = gload_wide32(q.lit, ll, false);
+            const u32 mn = early ? ml : 0u;
+            const Copy32 cb = gload_wide32(srcp, mn, srcp + 16 <= oend);
+            lds_store_wide32(ob + (r_ms - ll), ca, ll);
+            lds_store_wide32(ob + r_ms, cb, mn);
+            wave_mem_fence();
+            u64 done = ~pending | __ballot(early);
+            pending &= ~done;
+            u32 guard = 0;
+            while (pending) {
+                const bool ready = has_match && ((pending >> lane) & 1) && (need & ~done) == 0;
+                const u64 rmask = __ballot(ready);
+                if (rmask == 0 || ++guard > 70) return D_MALFORMED;
+                SEQ_STAT(stt.rounds++);
+                if (ready) {
+                    const lds_cp8 sp = (lds_cp8)(ob + (i32)src);                     // src >= -SEQ_ASM_PRE here
+                    Copy32 c; c.hi.lo = c.hi.hi = 0;
+                    c.lo = lds_ld128(sp);
+                    if (ml > 16) c.hi = lds_ld128(sp + (ml - 16));
+                    lds_store_wide32(ob + r_ms, c, ml);
+                }
+                wave_mem_fence();
+                done |= rmask;
+                pending &= ~rmask;
+            }
+            // flush: contiguous, 16 bytes per lane, exact end (bytes past the batch are never touched)
+            const u32 tot = (u32)total;
+            for (u32 c = (u32)lane * 16; c < tot; c += WAVE * 16) {
+                const u128 v = lds_ld128((lds_cp8)(ob + c));
+                if (c + 16 <= tot) st128(op + c, v);
+                else gstore_upto16(op + c, v, tot - c);
+            }
+            wave_mem_fence();
+            op += total;
+            return D_OK;
+        }
+    }
 
     // ---- 3. literals + early matches: every load is issued before the first store ----
     if (lit_rle >= 0) {

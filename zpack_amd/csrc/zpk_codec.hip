@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, 
         if (dbg && lane == 0) {
             u64* g = dbg + (u64)e * 8;
             g[0] = stt.t_parse; g[1] = stt.t_lit; g[2] = stt.t_dep; g[3] = stt.t_rounds;
-            g[4] = ((u64)stt.batches << 32) | stt.rounds; g[5] = ((u64)stt.coops << 32) | stt.redirects; g[6] = SEQ_T() - t_all;
+            g[4] = ((u64)stt.batches << 32) | stt.rounds; g[5] = ((u64)stt.coops << 32) | stt.asm_batches; g[6] = SEQ_T() - t_all;
             g[7] = ((u64)stt.fix_iters << 32) | stt.chunks;
             if (getenv_dbg2) { g[0] = stt.t_stage; g[1] = stt.t_walk1; g[2] = stt.t_fix; g[3] = stt.t_emit; g[4] = stt.t_tok; }
         }

@@ -93,6 +93,17 @@ typedef const ZPK_LDS u8* lds_cp8;
 __device__ __forceinline__ lds_cp8 to_lds(const u8* p) { return (lds_cp8)p; }
 __device__ __forceinline__ u32 lds_ld8(lds_cp8 p)  { return (u32)*p; }
 __device__ __forceinline__ u32 lds_ld16(lds_cp8 p) { return (u32)((const ZPK_LDS pk16*)p)->v; }
+typedef ZPK_LDS u8* lds_p8;
+__device__ __forceinline__ lds_p8 to_lds_rw(u8* p) { return (lds_p8)p; }
+__device__ __forceinline__ void lds_st8(lds_p8 p, u8 v)    { *p = v; }
+__device__ __forceinline__ void lds_st16(lds_p8 p, u16 v)  { ((ZPK_LDS pk16*)p)->v = v; }
+__device__ __forceinline__ void lds_st32(lds_p8 p, u32 v)  { ((ZPK_LDS pk32*)p)->v = v; }
+__device__ __forceinline__ void lds_st64(lds_p8 p, u64 v)  { ((ZPK_LDS pk64*)p)->v = v; }
+__device__ __forceinline__ void lds_st128(lds_p8 p, u128 v)
+{
+    v4u32 x; x.x = (u32)v.lo; x.y = (u32)(v.lo >> 32); x.z = (u32)v.hi; x.w = (u32)(v.hi >> 32);
+    *(ZPK_LDS v4u32_u*)p = x;
+}
 __device__ __forceinline__ u128 lds_ld128(lds_cp8 p)      // one ds_read_b128 at any byte offset
 {
     const v4u32 x = *(const ZPK_LDS v4u32_u*)p;
