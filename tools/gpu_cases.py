@@ -82,11 +82,14 @@ def run_case(name):
             t = time.time()
             codec.decode_batch_device(src, ddesc, n, dst, dres)
             torch.cuda.synchronize()
-            print("    iter %d: %.3f ms wall, k_lz4 %.3f ms" % (it, (time.time() - t) * 1e3, codec.kernel_ms(zpack_amd.K_LZ4)), flush=True)
+            print("    iter %d: %.3f ms wall, k_lz4 %.3f ms k_zstd %.3f ms" % (it, (time.time() - t) * 1e3, codec.kernel_ms(zpack_amd.K_LZ4), codec.kernel_ms(zpack_amd.K_ZSTD)), flush=True)
         if os.environ.get("ZPK_DEBUG_TIMING"):
             raw = codec.debug_read(n)
             m = lambda k: float(np.median(raw[:, k]))
-            if os.environ.get("ZPK_DEBUG_TIMING") == "2":
+            if method == 1:
+                print("    zstd cycles (median/entry): literals %.0f tables %.0f fse-parse %.0f exec %.0f total %.0f | sequences %.0f blocks %.0f"
+                      % (m(0), m(1), m(2), m(3), m(6), m(4), m(5)), flush=True)
+            elif os.environ.get("ZPK_DEBUG_TIMING") == "2":
                 print("    parse split (median cycles/entry): stage %.0f walk1 %.0f fix %.0f emit+scan %.0f token-fetch %.0f | fix iters %.0f chunks %.0f"
                       % (m(0), m(1), m(2), m(3), m(4), np.median(raw[:, 7] >> 32), np.median(raw[:, 7] & 0xffffffff)), flush=True)
             else:

@@ -18,6 +18,18 @@
 namespace zpk {
 
 // 256-byte sliding register window over a read-only byte stream
+// the window word of one lane: bytes [a, a+4) clipped to [lo, hi).  Out of line on purpose: the bit readers
+// inline into dozens of call sites, and this rarely-taken body (once per ~240 stream bytes) was most of the
+// Zstandard kernel's code size.
+__device__ __noinline__ u32 window_word(const u8* a, const u8* lo, const u8* hi)
+{
+    if (a >= lo && a + 4 <= hi) return ld32(a);
+    u32 v = 0;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) if (a + i >= lo && a + i < hi) v |= (u32)ld8(a + i) << (8 * i);
+    return v;
+}
+
 struct ByteWindow {
     u32 w;              // lane l holds bytes [base + 4l, base + 4l + 4)
     const u8* base;     // 4-byte aligned, uniform
@@ -27,14 +39,7 @@ struct ByteWindow {
     __device__ __forceinline__ void load(const u8* p, int lane)
     {
         base = (const u8*)((u64)p & ~(u64)3);
-        const u8* a = base + 4 * lane;
-        u32 v = 0;
-        if (a >= lo && a + 4 <= hi) v = ld32(a);
-        else {
-            #pragma unroll
-            for (int i = 0; i < 4; i++) if (a + i >= lo && a + i < hi) v |= (u32)ld8(a + i) << (8 * i);
-        }
-        w = v;
+        w = window_word(base + 4 * lane, lo, hi);
     }
     // uniform byte at uniform address p (refills when p leaves the window)
     __device__ __forceinline__ u32 byte(const u8* p, int lane)

@@ -188,10 +188,10 @@ __global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, 
     }
 }
 
-__global__ __launch_bounds__(ZSTD_WG_THREADS) void k_zstd(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
+__global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                           u8* dst, zpk_decode_result* __restrict__ res,
                                                           const u32* __restrict__ list, u32* __restrict__ counters,
-                                                          u8* __restrict__ lit_scratch)
+                                                          u8* __restrict__ lit_scratch, u64* __restrict__ dbg)
 {
     const int lane = lane_id();
     __shared__ ZstdShared sh;
@@ -205,7 +205,18 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS) void k_zstd(const u8* __restrict__
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
         Watchdog wd; wd.arm();
+#ifdef ZPK_STATS
+        ZstdStats zs = {};
+        const u64 t_all = SEQ_T();
+        DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, &zs);
+        if (dbg && lane == 0) {
+            u64* g = dbg + (u64)e * 8;
+            g[0] = zs.t_lit; g[1] = zs.t_tab; g[2] = zs.t_fse; g[3] = zs.t_exec; g[4] = zs.nseq; g[5] = zs.nblk; g[6] = SEQ_T() - t_all; g[7] = 0;
+        }
+#else
+        (void)dbg;
         DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane);
+#endif
         int status = o.rc == D_OK ? R_OK : R_DECOMPRESS_FAILED;               // lib/zpack_read.c:384-388
         finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
     }
@@ -351,7 +362,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_TRACE_STEP("k_lz4_wave");
     ZPK_KEV(ZPK_K_ZSTD, 0);
     if (!(skip & 4)) hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
-                       c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit);
+                       c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_dbg);
     ZPK_KEV(ZPK_K_ZSTD, 1);
     ZPK_TRACE_STEP("k_zstd");
     if (trace == 2) {

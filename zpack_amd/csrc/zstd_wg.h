@@ -25,23 +25,33 @@ namespace zpk {
 #define ZSTD_WG_THREADS 64
 #define ZSTD_BLOCK_MAX (128u << 10)
 #define ZSTD_LIT_SCRATCH ((128u << 10) + 64)
-#define ZSTD_GRID_MAX 1792            // 7 workgroups per CU (LDS-limited)
+#define ZSTD_GRID_MAX 2304            // 9 workgroups per CU (LDS-limited: 17.5 KiB each)
 
-struct FseEntry {          // 8 bytes: one LDS read per state transition
-    u16 next_base;         // new_state = next_base + read(nb_bits)
-    u8  nb_bits;
-    u8  add_bits;          // extra bits of the symbol's value
-    u32 base_value;        // LL/ML: value baseline; OF: 1 << code
-};
+// One FSE decode-table cell, packed into 32 bits (LDS is what limits how many entries a CU decodes at once):
+//   bits 0..9 next_base (new_state = next_base + read(nb_bits)), 10..13 nb_bits, 14..18 add_bits (extra bits
+//   of the symbol's value), 19..24 the symbol.  The value baseline comes from a per-symbol table.
+typedef u32 FseCell;
+__device__ __forceinline__ FseCell fse_cell(u32 next_base, u32 nb, u32 add_bits, u32 sym) { return next_base | (nb << 10) | (add_bits << 14) | (sym << 19); }
+__device__ __forceinline__ u32 cell_next(FseCell c) { return c & 1023u; }
+__device__ __forceinline__ u32 cell_nb(FseCell c)   { return (c >> 10) & 15u; }
+__device__ __forceinline__ u32 cell_add(FseCell c)  { return (c >> 14) & 31u; }
+__device__ __forceinline__ u32 cell_sym(FseCell c)  { return (c >> 19) & 63u; }
 
 struct alignas(16) ZstdShared {
-    FseEntry ll[512], ml[512], of[256];
-    FseEntry wt[64];                             // FSE table of the Huffman weights (accuracy log <= 6)
-    FseEntry dll[64], dml[64], dof[32];          // predefined distributions (built once per workgroup)
+    FseCell ll[512], ml[512], of[256];
+    FseCell dll[64], dml[64], dof[32];           // predefined distributions (built once per workgroup)
+    u32 symtab[2][64];                           // [0] literal-length, [1] match-length codes: baseline | extra bits << 24
+    u32 ofbase[32];                              // offset codes: 1 << code
     u16 huf[4096];                               // sym | nbits << 8
-    i16 ncount[3][64];
-    u8  spread[3][512];
-    u16 nextc[3][64];
+    union {
+        struct {                                 // table descriptions and construction scratch (block headers)
+            FseCell wt[64];                      // FSE table of the Huffman weights (accuracy log <= 6)
+            i16 ncount[3][64];
+            u8  spread[3][512];
+            u16 nextc[3][64];
+        };
+        u32 seqbuf[64 * 3];                      // one batch of decoded sequences: offset, match length, literal length
+    };
     u8  weights[256];
     u32 huf_max_bits;
     u32 huf_valid;
@@ -82,6 +92,27 @@ __device__ __forceinline__ u64 win_bits64(ByteWindow& win, const u8* start, i64 
     u32 w2 = (u32)__builtin_amdgcn_readlane((int)win.w, i + 2);
     u64 lo = ((u64)w1 << 32) | w0;
     return t ? (lo >> t) | ((u64)w2 << (64 - t)) : lo;
+}
+
+// 128 stream bits starting at bit `bitpos` (may be negative): lo = [bitpos, bitpos+64), hi = the next 64.
+// Backward streams only (the window is re-based so that it extends downwards).  Five v_readlane.
+__device__ __forceinline__ void win_bits128(ByteWindow& win, const u8* start, i64 bitpos, int lane, u64& lo, u64& hi)
+{
+    const u8* p = uni_ptr(start + (bitpos >> 3));         // floor
+    i64 d = (i64)(p - win.base);
+    if (d < 0 || d > 236) {
+        win.load((const u8*)(((u64)p & ~(u64)3) - 232), lane);
+        d = (i64)(p - win.base);
+    }
+    const int i = (int)uni((u32)(d >> 2)), t = (int)uni((u32)((d & 3) * 8 + (bitpos & 7)));      // t <= 31
+    const u32 w0 = (u32)__builtin_amdgcn_readlane((int)win.w, i);
+    const u32 w1 = (u32)__builtin_amdgcn_readlane((int)win.w, i + 1);
+    const u32 w2 = (u32)__builtin_amdgcn_readlane((int)win.w, i + 2);
+    const u32 w3 = (u32)__builtin_amdgcn_readlane((int)win.w, i + 3);
+    const u32 w4 = (u32)__builtin_amdgcn_readlane((int)win.w, i + 4);
+    const u64 a = ((u64)w1 << 32) | w0, b = ((u64)w3 << 32) | w2;
+    lo = t ? (a >> t) | (b << (64 - t)) : a;
+    hi = t ? (b >> t) | ((u64)w4 << (64 - t)) : b;
 }
 
 // backward bitstream (FSE payloads): bits are consumed from the top down; below bit 0 reads zero
@@ -180,57 +211,51 @@ __device__ inline int fse_read_ncount(ByteWindow& win, const u8* src, u64 size, 
 }
 
 // Build one decode table from normalized counts — executed by ONE lane (three tables are built by
-// three lanes side by side).  kind selects the value tables.  Returns false on a malformed distribution.
-__device__ inline bool fse_build_lane(FseEntry* tab, const i16* ncount, int nsym, int al, int kind, u8* spread, u16* nextc)
+// three lanes side by side).  symtab: per-symbol baseline | extra bits << 24 in LDS (null: offset codes or
+// Huffman weights, whose extra bits are the symbol itself resp. zero).  Returns false on a malformed
+// distribution.
+__device__ __noinline__ bool fse_build_lane(ZPK_LDS FseCell* tab, const ZPK_LDS i16* ncount, int nsym, int al, int kind, const ZPK_LDS u32* symtab,
+                                            ZPK_LDS u8* spread, ZPK_LDS u16* nextc)
 {
     const int size = 1 << al;
     int high = size;
+    #pragma unroll 1
     for (int s = 0; s < nsym; s++)
         if (ncount[s] == -1) { spread[--high] = (u8)s; nextc[s] = 1; }
     const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     int pos = 0;
+    #pragma unroll 1
     for (int s = 0; s < nsym; s++) {
         int f = ncount[s];
         if (f <= 0) continue;
         nextc[s] = (u16)f;
+        #pragma unroll 1
         for (int i = 0; i < f; i++) {
             spread[pos] = (u8)s;
             do { pos = (pos + step) & mask; } while (pos >= high);
         }
     }
     if (pos != 0) return false;
+    #pragma unroll 1
     for (int i = 0; i < size; i++) {
-        int s = spread[i];
-        u32 n = nextc[s]++;
-        int nb = al - highbit32(n);
-        FseEntry e;
-        e.nb_bits = (u8)nb;
-        e.next_base = (u16)((n << nb) - (u32)size);
-        if (kind == T_LL) { e.base_value = Z_LL_BASE[s]; e.add_bits = Z_LL_BITS[s]; }
-        else if (kind == T_ML) { e.base_value = Z_ML_BASE[s]; e.add_bits = Z_ML_BITS[s]; }
-        else if (kind == T_OF) { e.base_value = 1u << s; e.add_bits = (u8)s; }
-        else { e.base_value = (u32)s; e.add_bits = 0; }                 // Huffman weights
-        tab[i] = e;
+        const u32 s = spread[i];
+        const u32 n = nextc[s]++;
+        const u32 nb = (u32)al - (u32)highbit32(n);
+        const u32 add = symtab ? symtab[s] >> 24 : (kind == T_OF ? s : 0u);
+        tab[i] = fse_cell((n << nb) - (u32)size, nb, add, s);
     }
     return true;
 }
+#define LDSP(T, p) ((ZPK_LDS T*)(p))
 
-__device__ __forceinline__ FseEntry fse_rle_entry(int kind, u32 s)
+__device__ __forceinline__ FseCell fse_rle_cell(int kind, u32 s)
 {
-    FseEntry e; e.next_base = 0; e.nb_bits = 0;
-    if (kind == T_LL) { e.base_value = Z_LL_BASE[s]; e.add_bits = Z_LL_BITS[s]; }
-    else if (kind == T_ML) { e.base_value = Z_ML_BASE[s]; e.add_bits = Z_ML_BITS[s]; }
-    else { e.base_value = 1u << s; e.add_bits = (u8)s; }
-    return e;
+    const u32 add = kind == T_LL ? Z_LL_BITS[s] : (kind == T_ML ? Z_ML_BITS[s] : s);
+    return fse_cell(0, 0, add, s);
 }
 
-__device__ __forceinline__ FseEntry lds_entry(const FseEntry* tab, u32 state)
-{
-    u64 raw = *(const u64*)&tab[state];
-    raw = uni64(raw);
-    FseEntry e; __builtin_memcpy(&e, &raw, 8);
-    return e;
-}
+// uniform read of one cell (Huffman weight stream)
+__device__ __forceinline__ FseCell lds_cell(const FseCell* tab, u32 state) { return uni(tab[state]); }
 
 // ---- Huffman ------------------------------------------------------------------------------------
 
@@ -317,7 +342,7 @@ __device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* s
         __syncthreads();
         __shared__ u32 okb;
         lane0_guard();
-        if (lane == 0) okb = fse_build_lane(sh.wt, sh.ncount[0], nsym, al, 3, sh.spread[0], sh.nextc[0]) ? 1u : 0u;
+        if (lane == 0) okb = fse_build_lane(LDSP(FseCell, sh.wt), LDSP(i16, sh.ncount[0]), nsym, al, 3, nullptr, LDSP(u8, sh.spread[0]), LDSP(u16, sh.nextc[0])) ? 1u : 0u;
         __syncthreads();
         if (!okb) return -1;
         RevBits b;
@@ -326,19 +351,19 @@ __device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* s
         // two interleaved states; ends when an update over-reads (libzstd FSE_decompress tail)
         for (;;) {
             if (n > 253) return -1;
-            FseEntry e1 = lds_entry(sh.wt, s1);
+            const FseCell e1 = lds_cell(sh.wt, s1);
             lane0_guard();
-            if (lane == 0) sh.weights[n] = (u8)e1.base_value;
+            if (lane == 0) sh.weights[n] = (u8)cell_sym(e1);
             n++;
-            s1 = e1.next_base + b.read(win, e1.nb_bits, lane);
-            if (b.pos < 0) { FseEntry e2 = lds_entry(sh.wt, s2); if (lane == 0) sh.weights[n] = (u8)e2.base_value; n++; break; }
+            s1 = cell_next(e1) + b.read(win, (int)cell_nb(e1), lane);
+            if (b.pos < 0) { const FseCell e2 = lds_cell(sh.wt, s2); if (lane == 0) sh.weights[n] = (u8)cell_sym(e2); n++; break; }
             if (n > 253) return -1;
-            FseEntry e2 = lds_entry(sh.wt, s2);
+            const FseCell e2 = lds_cell(sh.wt, s2);
             lane0_guard();
-            if (lane == 0) sh.weights[n] = (u8)e2.base_value;
+            if (lane == 0) sh.weights[n] = (u8)cell_sym(e2);
             n++;
-            s2 = e2.next_base + b.read(win, e2.nb_bits, lane);
-            if (b.pos < 0) { FseEntry e3 = lds_entry(sh.wt, s1); if (lane == 0) sh.weights[n] = (u8)e3.base_value; n++; break; }
+            s2 = cell_next(e2) + b.read(win, (int)cell_nb(e2), lane);
+            if (b.pos < 0) { const FseCell e3 = lds_cell(sh.wt, s1); if (lane == 0) sh.weights[n] = (u8)cell_sym(e3); n++; break; }
         }
         used = 1 + csize;
     }
@@ -437,7 +462,15 @@ __device__ inline bool huf_decode_streams(const ZstdShared& sh, const u8* p, u64
 
 // ---- one compressed block ------------------------------------------------------------------------
 
+#ifdef ZPK_STATS
+struct ZstdStats { u64 t_lit, t_tab, t_fse, t_exec, nseq, nblk; };
+#define ZST(x) do { x; } while (0)
+#else
+struct ZstdStats { };
+#define ZST(x) do { } while (0)
+#endif
 struct ZFrameState {
+    ZstdStats* zs;
     Watchdog* wd;
     u64 rep0, rep1, rep2;
     bool seq_tables_valid;
@@ -448,11 +481,11 @@ struct ZFrameState {
 __device__ inline int read_seq_table(ZstdShared& sh, ByteWindow& win, int kind, int mode, const u8* src, u64 size,
                                      bool have_prev, int& al, int& pending_build, int& nsym_out, int lane)
 {
-    FseEntry* tab = kind == T_LL ? sh.ll : (kind == T_OF ? sh.of : sh.ml);
+    FseCell* tab = kind == T_LL ? sh.ll : (kind == T_OF ? sh.of : sh.ml);
     const int max_sym = kind == T_LL ? 35 : (kind == T_OF ? 31 : 52);
     const int max_al = kind == T_OF ? 8 : 9;
     if (mode == 0) {
-        const FseEntry* def = kind == T_LL ? sh.dll : (kind == T_OF ? sh.dof : sh.dml);
+        const FseCell* def = kind == T_LL ? sh.dll : (kind == T_OF ? sh.dof : sh.dml);
         const int n = kind == T_OF ? 32 : 64;
         for (int i = lane; i < n; i += WAVE) tab[i] = def[i];
         al = kind == T_OF ? 5 : 6;
@@ -463,7 +496,7 @@ __device__ inline int read_seq_table(ZstdShared& sh, ByteWindow& win, int kind, 
         u32 s = uld8(src);
         if ((int)s > max_sym) return -1;
         lane0_guard();
-        if (lane == 0) tab[0] = fse_rle_entry(kind, s);
+        if (lane == 0) tab[0] = fse_rle_cell(kind, s);
         al = 0;
         return 1;
     }
@@ -478,11 +511,152 @@ __device__ inline int read_seq_table(ZstdShared& sh, ByteWindow& win, int kind, 
     return have_prev ? 0 : -1;
 }
 
+// The sequences section of one block: FSE decode + execution.  Out of line, with its own register allocation
+// (inlined into the block parser the hot loop shared ~210 live VGPRs with header-parsing state); everything it
+// needs comes in through a small argument block, the tables through an LDS-typed pointer.
+struct ZSeqArgs {
+    const u8* p; u64 left; u64 nseq;
+    int al_ll, al_of, al_ml;
+    u32 rep0, rep1, rep2;                 // in/out
+    const u8* lit; u64 lit_size; int lit_rle; u32 lit_rle_byte;
+    u8* op; u8* oend; u8* frame_lo;       // op: in/out
+    u64 lit_pos;                          // out: literals consumed
+    u64 deadline; int timed_out;
+    ZstdStats* zs;
+};
+__device__ __noinline__ int zstd_sequences(ZPK_LDS ZstdShared* sh, ZSeqArgs* a, int lane)
+{
+    ByteWindow win;
+    const u8* const p = uni_ptr(a->p); const u64 left = uni64(a->left), nseq = uni64(a->nseq);
+    const u8* const lit = uni_ptr(a->lit); const u64 lit_size = uni64(a->lit_size);
+    const bool lit_rle = a->lit_rle != 0; const u32 lit_rle_byte = a->lit_rle_byte;
+    u8* op = uni_ptr(a->op); u8* const oend = uni_ptr(a->oend); u8* const frame_lo = uni_ptr(a->frame_lo);
+    u64 lit_pos = 0;
+    u64 zt0 = SEQ_T(); (void)zt0;
+    {
+        RevBits b;
+        if (!b.init(win, p, left, lane)) return D_MALFORMED;
+        const u32 sll = b.read(win, a->al_ll, lane);
+        const u32 sof = b.read(win, a->al_of, lane);
+        const u32 sml = b.read(win, a->al_ml, lane);
+        // ---- the three FSE chains run side by side in lanes ----
+        // Lane t in {0,1,2} (OF, ML, LL) extracts its symbol's value bits, lane 7-t the bits of the same chain's
+        // state update: the six fields of a sequence sit in the stream in exactly that lane order (OF, ML, LL
+        // values, then LL, ML, OF states), so their bit offsets are one DPP prefix sum over lanes 0..7, every
+        // field is cut out of a uniform 128-bit container with per-lane shifts, and row_half_mirror hands the new
+        // state to the partner lane.  One ds_read_b64 fetches all three next table entries.  The critical path
+        // per sequence is table read -> ~15 dependent vector instructions -> table read, instead of ~7 serial
+        // scalar bit-reader calls.
+        const int role = lane < 3 ? lane : 7 - lane;                      // 0 OF, 1 ML, 2 LL (lanes 0..2 and 7..5)
+        const bool chain = lane < 3 || (lane >= 5 && lane < 8);
+        const ZPK_LDS u32* const tab = role == 0 ? sh->of : (role == 1 ? sh->ml : sh->ll);   // other lanes: harmless reads of ll[]
+        // value baselines: one table per chain, no branch (offset codes: 1 << code, full 32 bits)
+        const ZPK_LDS u32* const symt = role == 0 ? sh->ofbase : sh->symtab[role == 2 ? 0 : 1];
+        const u32 symmask = role == 0 ? 0xFFFFFFFFu : 0xFFFFFFu;
+        FseCell cell = tab[role == 0 ? sof : (role == 1 ? sml : (chain ? sll : 0u))];
+        u32 rep0 = a->rep0, rep1 = a->rep1, rep2 = a->rep2;    // live in lane 0
+        ZPK_LDS u32* const seqbuf = sh->seqbuf;
+        // uniform stream position, 32-bit (a block is at most 128 KiB): bits not yet consumed; may go negative
+        const u8* const start = b.start;
+        i32 pos = (i32)uni((u32)b.pos);
+        i32 wb = (i32)uni((u32)(i64)(win.base - start));       // window base as a byte offset from the stream start
+
+        for (u64 base = 0; base < nseq; base += WAVE) {
+            const int cnt = (int)(nseq - base < WAVE ? nseq - base : WAVE);
+            if (__builtin_amdgcn_s_memrealtime() > a->deadline) { a->timed_out = 1; return D_MALFORMED; }
+            wave_mem_fence();
+            for (int k = 0; k < cnt; k++) {
+                // ---- 128-bit container: stream bits [pos-128, pos), five v_readlane out of the register window ----
+                const i32 lowbit = pos - 128;
+                const i32 byte = lowbit >> 3;                                   // floor
+                i32 d = byte - wb;
+                if ((u32)d > 236u) {
+                    win.load((const u8*)(((u64)(start + byte) & ~(u64)3) - 232), lane);
+                    wb = (i32)uni((u32)(i64)(win.base - start));
+                    d = byte - wb;
+                }
+                const int wi = d >> 2;
+                const u32 t = (u32)(d & 3) * 8u + (u32)(lowbit & 7);            // <= 31
+                const u32 w0 = (u32)__builtin_amdgcn_readlane((int)win.w, wi), w1 = (u32)__builtin_amdgcn_readlane((int)win.w, wi + 1);
+                const u32 w2 = (u32)__builtin_amdgcn_readlane((int)win.w, wi + 2), w3 = (u32)__builtin_amdgcn_readlane((int)win.w, wi + 3);
+                const u32 w4 = (u32)__builtin_amdgcn_readlane((int)win.w, wi + 4);
+                const u64 qa = ((u64)w1 << 32) | w0, qb = ((u64)w3 << 32) | w2, qc = ((u64)w4 << 32) | w3;
+                const u64 clo = (qa >> t) | ((qb << 1) << (63u - t));           // [pos-128, pos-64)
+                const u64 chi = (u64)(u32)(qb >> t) | ((qc >> t) << 32);        // [pos-64, pos)
+                // ---- field widths and offsets ----
+                const u32 sym = cell_sym(cell);
+                const u32 e_base = symt[sym];                                    // consumed last
+                u32 n = lane < 3 ? cell_add(cell) : cell_nb(cell);
+                n = chain ? n : 0u;
+                u32 s = n;
+                s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false);
+                s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false);
+                s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false);
+                const u32 off = s - n;                                         // bits of the fields before this lane's
+                const u32 total = (u32)__builtin_amdgcn_readlane((int)s, 7);
+                const u32 o6 = off & 63u;
+                const u64 xa = (chi << o6) | ((clo >> 1) >> (63u - o6)), xb = clo << o6;
+                const u64 x = off < 64 ? xa : xb;
+                const u32 bits = (u32)((x >> 1) >> (63u - n));                  // n = 0 -> 0
+                // libzstd 1.4.9 updates all three states after every sequence, the last included
+                const u32 nst = cell_next(cell) + bits;                        // lanes 5..7: next state
+                const u32 nst_m = (u32)__builtin_amdgcn_update_dpp(0, (int)nst, 0x141, 0xf, 0xf, false);   // row_half_mirror
+                cell = tab[lane < 3 ? nst_m : (chain ? nst : 0u)];
+                const u32 val = (e_base & symmask) + bits;                     // lanes 0..2: offset value, match length, literal length
+                // repeat offsets (RFC 8878 3.1.1.5), on lane 0
+                const u32 llv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE6, 0xf, 0xf, false);      // quad_perm [2,1,2,3]
+                u32 offset;
+                {
+                    const bool big = val > 3;
+                    const u32 idx = val - 1 + (llv == 0 ? 1u : 0u);           // 0..3 when !big
+                    u32 tt = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                    if (tt == 0) tt = 1;                                       // libzstd: forced to 1 on corrupt input
+                    offset = big ? val - 3 : (idx == 0 ? rep0 : tt);
+                    const bool shift = big || idx != 0;
+                    const u32 n2 = (big || idx != 1) ? rep1 : rep2;
+                    if (shift) { rep2 = n2; rep1 = rep0; rep0 = offset; }
+                }
+                if (lane < 3) seqbuf[k * 3 + lane] = lane == 0 ? offset : val;
+                pos = (i32)uni((u32)(pos - (i32)total));
+            }
+            wave_mem_fence();
+            u32 my_ll = 0, my_ml = 0; u64 my_off = 0;
+            if (lane < cnt) { my_off = seqbuf[lane * 3]; my_ml = seqbuf[lane * 3 + 1]; my_ll = seqbuf[lane * 3 + 2]; }
+            ZST({ u64 t = SEQ_T(); a->zs->t_fse += t - zt0; zt0 = t; });
+            // ---- execute the batch lane-parallel (seq_exec.h): literal sources are a prefix sum over the literal buffer
+            {
+                u32 xl = lane < cnt ? my_ll : 0u;
+                #pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)xl, d, 64); if (lane >= d) xl += y; }
+                const u64 lit_total = (u32)__builtin_amdgcn_readlane((int)xl, 63);
+                if (lit_total > lit_size - lit_pos) return D_MALFORMED;
+                if (__ballot(lane < cnt && (my_off == 0 || my_off > 0xFFFFFFFFull)) != 0) return D_MALFORMED;
+                SeqBatch q;
+                q.lit = lit + lit_pos + (xl - (lane < cnt ? my_ll : 0u));
+                q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = (u32)my_off;
+                SeqStats stt = {};
+                (void)stt;
+                const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt);
+                if (rc != D_OK) { a->op = op; return rc; }
+                lit_pos += lit_total;
+                ZST({ u64 t = SEQ_T(); a->zs->t_exec += t - zt0; zt0 = t; });
+            }
+        }
+        a->rep0 = (u32)__builtin_amdgcn_readfirstlane((int)rep0); a->rep1 = (u32)__builtin_amdgcn_readfirstlane((int)rep1);
+        a->rep2 = (u32)__builtin_amdgcn_readfirstlane((int)rep2);
+        if (pos > 0) return D_MALFORMED;             // libzstd 1.4.9: the stream must not be under-consumed
+    
+    }
+    a->op = op; a->lit_pos = lit_pos;
+    return D_OK;
+}
+
 __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src, u64 size, const u8* rd_hi,
                                  u8* dst, u64 dst_cap, u8* frame_lo, u8* lit_buf, u64& produced, int lane)
 {
     ByteWindow win;
     if (size < 3) return D_MALFORMED;
+    u64 zt0 = SEQ_T(); (void)zt0;
     // ---- literals section ----
     const u32 b0 = uld8(src);
     const u32 type = b0 & 3, fmt = (b0 >> 2) & 3;
@@ -517,6 +691,7 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         wave_mem_fence();
         lit_size = regen; used = hl + csize;
     }
+    ZST({ u64 t = SEQ_T(); fs.zs->t_lit += t - zt0; zt0 = t; fs.zs->nblk++; });
     // ---- sequences header ----
     const u8* p = src + used;
     u64 left = size - used;
@@ -548,72 +723,28 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         {   // the FSE-described tables are built side by side, one lane each
             bool ok = true;
             lane0_guard();
-            if (lane == T_LL && (pending & (1 << T_LL))) ok = fse_build_lane(sh.ll, sh.ncount[T_LL], ns[T_LL], fs.al_ll, T_LL, sh.spread[T_LL], sh.nextc[T_LL]);
-            if (lane == T_OF && (pending & (1 << T_OF))) ok = fse_build_lane(sh.of, sh.ncount[T_OF], ns[T_OF], fs.al_of, T_OF, sh.spread[T_OF], sh.nextc[T_OF]);
-            if (lane == T_ML && (pending & (1 << T_ML))) ok = fse_build_lane(sh.ml, sh.ncount[T_ML], ns[T_ML], fs.al_ml, T_ML, sh.spread[T_ML], sh.nextc[T_ML]);
+            if (lane == T_LL && (pending & (1 << T_LL))) ok = fse_build_lane(LDSP(FseCell, sh.ll), LDSP(i16, sh.ncount[T_LL]), ns[T_LL], fs.al_ll, T_LL, LDSP(u32, sh.symtab[0]), LDSP(u8, sh.spread[T_LL]), LDSP(u16, sh.nextc[T_LL]));
+            if (lane == T_OF && (pending & (1 << T_OF))) ok = fse_build_lane(LDSP(FseCell, sh.of), LDSP(i16, sh.ncount[T_OF]), ns[T_OF], fs.al_of, T_OF, nullptr, LDSP(u8, sh.spread[T_OF]), LDSP(u16, sh.nextc[T_OF]));
+            if (lane == T_ML && (pending & (1 << T_ML))) ok = fse_build_lane(LDSP(FseCell, sh.ml), LDSP(i16, sh.ncount[T_ML]), ns[T_ML], fs.al_ml, T_ML, LDSP(u32, sh.symtab[1]), LDSP(u8, sh.spread[T_ML]), LDSP(u16, sh.nextc[T_ML]));
             if (__ballot(!ok) != 0) return D_MALFORMED;
         }
         __syncthreads();
         fs.seq_tables_valid = true;
+        ZST({ u64 t = SEQ_T(); fs.zs->t_tab += t - zt0; zt0 = t; fs.zs->nseq += nseq; });
 
-        RevBits b;
-        if (!b.init(win, p, left, lane)) return D_MALFORMED;
-        u32 sll = b.read(win, fs.al_ll, lane);
-        u32 sof = b.read(win, fs.al_of, lane);
-        u32 sml = b.read(win, fs.al_ml, lane);
-        FseEntry ell = lds_entry(sh.ll, sll), eof_ = lds_entry(sh.of, sof), eml = lds_entry(sh.ml, sml);
-
-        for (u64 base = 0; base < nseq; base += WAVE) {
-            const int cnt = (int)(nseq - base < WAVE ? nseq - base : WAVE);
-            u32 my_ll = 0, my_ml = 0; u64 my_off = 0;
-            // ---- C1: parse up to 64 sequences wave-uniformly, sequence k lands in lane k's registers
-            if (fs.wd->expired()) return D_MALFORMED;
-            for (int k = 0; k < cnt; k++) {
-                const u32 ofb = eof_.add_bits;
-                u64 of_val = (u64)eof_.base_value + b.read(win, (int)ofb, lane);
-                u32 ml = eml.base_value + b.read(win, eml.add_bits, lane);
-                u32 ll = ell.base_value + b.read(win, ell.add_bits, lane);
-                u64 offset;
-                if (of_val > 3) {
-                    offset = of_val - 3;
-                    fs.rep2 = fs.rep1; fs.rep1 = fs.rep0; fs.rep0 = offset;
-                } else {
-                    u32 idx = (u32)of_val - 1 + (ell.base_value == 0 && ell.add_bits == 0 ? 1u : 0u);
-                    if (idx == 0) offset = fs.rep0;
-                    else {
-                        u64 t = idx == 3 ? fs.rep0 - 1 : (idx == 1 ? fs.rep1 : fs.rep2);
-                        if (t == 0) t = 1;                                   // libzstd: forced to 1 on corrupt input
-                        if (idx != 1) fs.rep2 = fs.rep1;
-                        fs.rep1 = fs.rep0;
-                        fs.rep0 = offset = t;
-                    }
-                }
-                // libzstd 1.4.9 updates all three states after every sequence, the last included
-                sll = ell.next_base + b.read(win, ell.nb_bits, lane);
-                sml = eml.next_base + b.read(win, eml.nb_bits, lane);
-                sof = eof_.next_base + b.read(win, eof_.nb_bits, lane);
-                ell = lds_entry(sh.ll, sll); eml = lds_entry(sh.ml, sml); eof_ = lds_entry(sh.of, sof);
-                if (lane == k) { my_ll = ll; my_ml = ml; my_off = offset; }
-            }
-            // ---- execute the batch lane-parallel (seq_exec.h): literal sources are a prefix sum over the literal buffer
-            {
-                u32 xl = lane < cnt ? my_ll : 0u;
-                #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { u32 y = (u32)__shfl_up((int)xl, d, 64); if (lane >= d) xl += y; }
-                const u64 lit_total = (u32)__builtin_amdgcn_readlane((int)xl, 63);
-                if (lit_total > lit_size - lit_pos) return D_MALFORMED;
-                if (__ballot(lane < cnt && (my_off == 0 || my_off > 0xFFFFFFFFull)) != 0) return D_MALFORMED;
-                SeqBatch q;
-                q.lit = lit + lit_pos + (xl - (lane < cnt ? my_ll : 0u));
-                q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = (u32)my_off;
-                SeqStats stt = {};
-                (void)stt;
-                const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt);
-                if (rc != D_OK) { produced = (u64)(op - dst); return rc; }
-                lit_pos += lit_total;
-            }
-        }
-        if (b.pos > 0) return D_MALFORMED;           // libzstd 1.4.9: the stream must not be under-consumed
+        ZSeqArgs sa;
+        sa.p = p; sa.left = left; sa.nseq = nseq;
+        sa.al_ll = fs.al_ll; sa.al_of = fs.al_of; sa.al_ml = fs.al_ml;
+        sa.rep0 = (u32)fs.rep0; sa.rep1 = (u32)fs.rep1; sa.rep2 = (u32)fs.rep2;
+        sa.lit = lit; sa.lit_size = lit_size; sa.lit_rle = lit_rle ? 1 : 0; sa.lit_rle_byte = lit_rle_byte;
+        sa.op = op; sa.oend = oend; sa.frame_lo = frame_lo; sa.lit_pos = 0;
+        sa.deadline = fs.wd->deadline; sa.timed_out = 0; sa.zs = fs.zs;
+        const int src_rc = zstd_sequences((ZPK_LDS ZstdShared*)&sh, &sa, lane);
+        if (sa.timed_out) fs.wd->fired = true;
+        op = sa.op;
+        if (src_rc != D_OK) { produced = (u64)(op - dst); return src_rc; }
+        fs.rep0 = sa.rep0; fs.rep1 = sa.rep1; fs.rep2 = sa.rep2;
+        lit_pos = sa.lit_pos;
     }
     const u64 rest = lit_size - lit_pos;
     if (rest > (u64)(oend - op)) { produced = (u64)(op - dst); return D_DST_FULL; }
@@ -630,18 +761,20 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
 
 __device__ inline void zstd_build_defaults(ZstdShared& sh, int lane)
 {
-    for (int i = lane; i < 36; i += WAVE) sh.ncount[T_LL][i] = Z_LL_DEF[i];
+    for (int i = lane; i < 36; i += WAVE) { sh.ncount[T_LL][i] = Z_LL_DEF[i]; sh.symtab[0][i] = Z_LL_BASE[i] | ((u32)Z_LL_BITS[i] << 24); }
     for (int i = lane; i < 29; i += WAVE) sh.ncount[T_OF][i] = Z_OF_DEF[i];
-    for (int i = lane; i < 53; i += WAVE) sh.ncount[T_ML][i] = Z_ML_DEF[i];
+    for (int i = lane; i < 32; i += WAVE) sh.ofbase[i] = 1u << i;
+    for (int i = lane; i < 53; i += WAVE) { sh.ncount[T_ML][i] = Z_ML_DEF[i]; sh.symtab[1][i] = Z_ML_BASE[i] | ((u32)Z_ML_BITS[i] << 24); }
     __syncthreads();
     lane0_guard();
-    if (lane == T_LL) fse_build_lane(sh.dll, sh.ncount[T_LL], 36, 6, T_LL, sh.spread[T_LL], sh.nextc[T_LL]);
-    if (lane == T_OF) fse_build_lane(sh.dof, sh.ncount[T_OF], 29, 5, T_OF, sh.spread[T_OF], sh.nextc[T_OF]);
-    if (lane == T_ML) fse_build_lane(sh.dml, sh.ncount[T_ML], 53, 6, T_ML, sh.spread[T_ML], sh.nextc[T_ML]);
+    if (lane == T_LL) fse_build_lane(LDSP(FseCell, sh.dll), LDSP(i16, sh.ncount[T_LL]), 36, 6, T_LL, LDSP(u32, sh.symtab[0]), LDSP(u8, sh.spread[T_LL]), LDSP(u16, sh.nextc[T_LL]));
+    if (lane == T_OF) fse_build_lane(LDSP(FseCell, sh.dof), LDSP(i16, sh.ncount[T_OF]), 29, 5, T_OF, nullptr, LDSP(u8, sh.spread[T_OF]), LDSP(u16, sh.nextc[T_OF]));
+    if (lane == T_ML) fse_build_lane(LDSP(FseCell, sh.dml), LDSP(i16, sh.ncount[T_ML]), 53, 6, T_ML, LDSP(u32, sh.symtab[1]), LDSP(u8, sh.spread[T_ML]), LDSP(u16, sh.nextc[T_ML]));
     __syncthreads();
 }
 
-__device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u8* lit_buf, int lane)
+__device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u8* lit_buf, int lane,
+                                             ZstdStats* zs = nullptr)
 {
     DecodeOut r; r.rc = D_OK; r.produced = 0;
     const u8* ip = src; const u8* iend = src + src_size;
@@ -686,7 +819,7 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const
         ip += fn;
 
         ZFrameState fs;
-        fs.wd = &wd;
+        fs.wd = &wd; fs.zs = zs;
         fs.rep0 = 1; fs.rep1 = 4; fs.rep2 = 8; fs.seq_tables_valid = false; fs.al_ll = fs.al_of = fs.al_ml = 0;
         lane0_guard();
         if (lane == 0) sh.huf_valid = 0;
