@@ -25,7 +25,7 @@ namespace zpk {
 #define ZSTD_WG_THREADS 64
 #define ZSTD_BLOCK_MAX (128u << 10)
 #define ZSTD_LIT_SCRATCH ((128u << 10) + 64)
-#define ZSTD_GRID_MAX 2304            // 9 workgroups per CU (LDS-limited: 17.5 KiB each)
+#define ZSTD_GRID_MAX 3072            // 12 workgroups per CU (LDS-limited: 13 KiB each)
 
 // One FSE decode-table cell, packed into 32 bits (LDS is what limits how many entries a CU decodes at once):
 //   bits 0..9 next_base (new_state = next_base + read(nb_bits)), 10..13 nb_bits, 14..18 add_bits (extra bits
@@ -40,9 +40,10 @@ __device__ __forceinline__ u32 cell_sym(FseCell c)  { return (c >> 19) & 63u; }
 struct alignas(16) ZstdShared {
     FseCell ll[512], ml[512], of[256];
     FseCell dll[64], dml[64], dof[32];           // predefined distributions (built once per workgroup)
-    u32 symtab[2][64];                           // [0] literal-length, [1] match-length codes: baseline | extra bits << 24
+    u32 symtab_ll[36], symtab_ml[54];            // literal-length / match-length codes: baseline | extra bits << 24
     u32 ofbase[32];                              // offset codes: 1 << code
-    u16 huf[4096];                               // sym | nbits << 8
+    u8  huf[4096];                               // symbol of every max_bits-bit prefix (the code length follows from huf_rank)
+    u32 huf_rank[16];                            // [w] first table index of weight class w (1..max_bits), ~0 above: nbits = max_bits + 1 - w
     union {
         struct {                                 // table descriptions and construction scratch (block headers)
             FseCell wt[64];                      // FSE table of the Huffman weights (accuracy log <= 6)
@@ -51,6 +52,7 @@ struct alignas(16) ZstdShared {
             u16 nextc[3][64];
         };
         u32 seqbuf[64 * 3];                      // one batch of decoded sequences: offset, match length, literal length
+        struct { u16 sym_start[256]; u32 huf_cnt[16]; };   // Huffman table construction (after the weights are known)
     };
     u8  weights[256];
     u32 huf_max_bits;
@@ -262,18 +264,19 @@ __device__ __forceinline__ FseCell lds_cell(const FseCell* tab, u32 state) { ret
 // weights[0..n) are in LDS (n includes the implied last weight).  Whole wave; returns false if malformed.
 __device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
 {
-    // rank counts + weight sum by lane 0 (n <= 256)
-    __shared__ u32 rank_start[16];
+    // rank counts + weight sum by lane 0 (n <= 256); counters live in LDS (dynamically indexed private arrays
+    // cost registers this kernel does not have)
     __shared__ u32 ok_flag;
+    if (lane < 16) { sh.huf_cnt[lane] = 0; sh.huf_rank[lane] = 0xFFFFFFFFu; }
+    __syncthreads();
     lane0_guard();
     if (lane == 0) {
-        u32 cnt[14];
-        for (int i = 0; i < 14; i++) cnt[i] = 0;
         u32 sum = 0; bool ok = true;
+        #pragma unroll 1
         for (int i = 0; i < n; i++) {
             u32 w = sh.weights[i];
             if (w > 12) { ok = false; break; }
-            cnt[w]++;
+            sh.huf_cnt[w]++;
             if (w) sum += 1u << (w - 1);
         }
         int mb = 0;
@@ -281,10 +284,11 @@ __device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
             if (sum == 0 || (sum & (sum - 1))) ok = false;
             else { mb = highbit32(sum); if (mb < 1 || mb > 12) ok = false; }
         }
-        if (ok && (cnt[1] < 2 || (cnt[1] & 1))) ok = false;          // libzstd HUF_readStats
+        if (ok && (sh.huf_cnt[1] < 2 || (sh.huf_cnt[1] & 1))) ok = false;          // libzstd HUF_readStats
         if (ok) {
             u32 pos = 0;
-            for (int w = 1; w <= mb; w++) { rank_start[w] = pos; pos += cnt[w] << (w - 1); }
+            #pragma unroll 1
+            for (int w = 1; w <= mb; w++) { sh.huf_rank[w] = pos; pos += sh.huf_cnt[w] << (w - 1); }
             sh.huf_max_bits = (u32)mb;
         }
         ok_flag = ok ? 1u : 0u;
@@ -293,24 +297,24 @@ __device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
     if (!ok_flag) return false;
     const int mb = (int)sh.huf_max_bits;
     // fill: symbols of one weight take consecutive ranges in natural order -> serial over symbols per
-    // weight for the range starts (lane 0), then all lanes fill the ranges
-    __shared__ u16 sym_start[256];
+    // weight for the range starts (lane 0, running starts in huf_cnt), then all lanes fill the ranges
+    if (lane < 16) sh.huf_cnt[lane] = sh.huf_rank[lane];
+    __syncthreads();
     lane0_guard();
     if (lane == 0) {
-        u32 st[14];
-        for (int w = 1; w <= mb; w++) st[w] = rank_start[w];
+        #pragma unroll 1
         for (int i = 0; i < n; i++) {
             u32 w = sh.weights[i];
-            if (w) { sym_start[i] = (u16)st[w]; st[w] += 1u << (w - 1); }
+            if (w) { const u32 st = sh.huf_cnt[w]; sh.sym_start[i] = (u16)st; sh.huf_cnt[w] = st + (1u << (w - 1)); }
         }
     }
     __syncthreads();
+    #pragma unroll 1
     for (int i = 0; i < n; i++) {
         u32 w = sh.weights[i];
         if (!w) continue;
-        u32 len = 1u << (w - 1), base = sym_start[i];
-        u16 ent = (u16)((u32)i | ((u32)(mb + 1 - (int)w) << 8));
-        for (u32 k = lane; k < len; k += WAVE) sh.huf[base + k] = ent;
+        u32 len = 1u << (w - 1), base = sh.sym_start[i];
+        for (u32 k = lane; k < len; k += WAVE) sh.huf[base + k] = (u8)i;
     }
     __syncthreads();
     sh.huf_valid = 1;
@@ -446,13 +450,21 @@ __device__ inline bool huf_decode_streams(const ZstdShared& sh, const u8* p, u64
         if (ssz == 0 || sp[ssz - 1] == 0) bad = true;
         else {
             const int mb = (int)sh.huf_max_bits;
+            // code length of a table index: max_bits + 1 - (weight class), the class by comparing against the
+            // (uniform) class starts — runs beside the symbol's LDS read instead of widening the table to 16 bits
+            u32 rk[11];
+            #pragma unroll
+            for (int w = 0; w < 11; w++) rk[w] = uni(sh.huf_rank[w + 2]);
             LaneBits b; b.init(sp, ssz, rd_hi, highbit32(sp[ssz - 1]));
             for (u64 i = 0; i < cnt; i++) {
                 if ((i & 4095) == 4095 && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
                 u32 idx = b.peek(b.pos - mb, mb);              // zeros below bit 0
-                u32 e = sh.huf[idx];
-                out[i] = (u8)e;
-                b.pos -= (i64)(e >> 8);
+                const u32 sym = sh.huf[idx];
+                u32 nb = (u32)mb;
+                #pragma unroll
+                for (int w = 0; w < 11; w++) nb -= idx >= rk[w] ? 1u : 0u;
+                out[i] = (u8)sym;
+                b.pos -= (i64)nb;
             }
             if (b.pos != 0) bad = true;              // libzstd: BIT_endOfDStream required
         }
@@ -551,7 +563,7 @@ __device__ __noinline__ int zstd_sequences(ZPK_LDS ZstdShared* sh, ZSeqArgs* a, 
         const bool chain = lane < 3 || (lane >= 5 && lane < 8);
         const ZPK_LDS u32* const tab = role == 0 ? sh->of : (role == 1 ? sh->ml : sh->ll);   // other lanes: harmless reads of ll[]
         // value baselines: one table per chain, no branch (offset codes: 1 << code, full 32 bits)
-        const ZPK_LDS u32* const symt = role == 0 ? sh->ofbase : sh->symtab[role == 2 ? 0 : 1];
+        const ZPK_LDS u32* const symt = role == 0 ? sh->ofbase : (role == 2 ? sh->symtab_ll : sh->symtab_ml);
         const u32 symmask = role == 0 ? 0xFFFFFFFFu : 0xFFFFFFu;
         FseCell cell = tab[role == 0 ? sof : (role == 1 ? sml : (chain ? sll : 0u))];
         u32 rep0 = a->rep0, rep1 = a->rep1, rep2 = a->rep2;    // live in lane 0
@@ -723,9 +735,15 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         {   // the FSE-described tables are built side by side, one lane each
             bool ok = true;
             lane0_guard();
-            if (lane == T_LL && (pending & (1 << T_LL))) ok = fse_build_lane(LDSP(FseCell, sh.ll), LDSP(i16, sh.ncount[T_LL]), ns[T_LL], fs.al_ll, T_LL, LDSP(u32, sh.symtab[0]), LDSP(u8, sh.spread[T_LL]), LDSP(u16, sh.nextc[T_LL]));
-            if (lane == T_OF && (pending & (1 << T_OF))) ok = fse_build_lane(LDSP(FseCell, sh.of), LDSP(i16, sh.ncount[T_OF]), ns[T_OF], fs.al_of, T_OF, nullptr, LDSP(u8, sh.spread[T_OF]), LDSP(u16, sh.nextc[T_OF]));
-            if (lane == T_ML && (pending & (1 << T_ML))) ok = fse_build_lane(LDSP(FseCell, sh.ml), LDSP(i16, sh.ncount[T_ML]), ns[T_ML], fs.al_ml, T_ML, LDSP(u32, sh.symtab[1]), LDSP(u8, sh.spread[T_ML]), LDSP(u16, sh.nextc[T_ML]));
+            // one call, three lanes: the per-lane arguments select the table (a call per table would serialise them)
+            const int kd = lane < 3 ? lane : 0;
+            const int kal = kd == T_LL ? fs.al_ll : (kd == T_OF ? fs.al_of : fs.al_ml);
+            const int kns = kd == T_LL ? ns[T_LL] : (kd == T_OF ? ns[T_OF] : ns[T_ML]);
+            FseCell* const ktab = kd == T_LL ? sh.ll : (kd == T_OF ? sh.of : sh.ml);
+            const u32* const ksym = kd == T_LL ? sh.symtab_ll : sh.symtab_ml;
+            if (lane < 3 && (pending & (1 << lane)))
+                ok = fse_build_lane(LDSP(FseCell, ktab), LDSP(i16, sh.ncount[kd]), kns, kal, kd, kd == T_OF ? (const ZPK_LDS u32*)nullptr : LDSP(u32, ksym),
+                                    LDSP(u8, sh.spread[kd]), LDSP(u16, sh.nextc[kd]));
             if (__ballot(!ok) != 0) return D_MALFORMED;
         }
         __syncthreads();
@@ -761,15 +779,20 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
 
 __device__ inline void zstd_build_defaults(ZstdShared& sh, int lane)
 {
-    for (int i = lane; i < 36; i += WAVE) { sh.ncount[T_LL][i] = Z_LL_DEF[i]; sh.symtab[0][i] = Z_LL_BASE[i] | ((u32)Z_LL_BITS[i] << 24); }
+    for (int i = lane; i < 36; i += WAVE) { sh.ncount[T_LL][i] = Z_LL_DEF[i]; sh.symtab_ll[i] = Z_LL_BASE[i] | ((u32)Z_LL_BITS[i] << 24); }
     for (int i = lane; i < 29; i += WAVE) sh.ncount[T_OF][i] = Z_OF_DEF[i];
     for (int i = lane; i < 32; i += WAVE) sh.ofbase[i] = 1u << i;
-    for (int i = lane; i < 53; i += WAVE) { sh.ncount[T_ML][i] = Z_ML_DEF[i]; sh.symtab[1][i] = Z_ML_BASE[i] | ((u32)Z_ML_BITS[i] << 24); }
+    for (int i = lane; i < 53; i += WAVE) { sh.ncount[T_ML][i] = Z_ML_DEF[i]; sh.symtab_ml[i] = Z_ML_BASE[i] | ((u32)Z_ML_BITS[i] << 24); }
     __syncthreads();
     lane0_guard();
-    if (lane == T_LL) fse_build_lane(LDSP(FseCell, sh.dll), LDSP(i16, sh.ncount[T_LL]), 36, 6, T_LL, LDSP(u32, sh.symtab[0]), LDSP(u8, sh.spread[T_LL]), LDSP(u16, sh.nextc[T_LL]));
-    if (lane == T_OF) fse_build_lane(LDSP(FseCell, sh.dof), LDSP(i16, sh.ncount[T_OF]), 29, 5, T_OF, nullptr, LDSP(u8, sh.spread[T_OF]), LDSP(u16, sh.nextc[T_OF]));
-    if (lane == T_ML) fse_build_lane(LDSP(FseCell, sh.dml), LDSP(i16, sh.ncount[T_ML]), 53, 6, T_ML, LDSP(u32, sh.symtab[1]), LDSP(u8, sh.spread[T_ML]), LDSP(u16, sh.nextc[T_ML]));
+    {
+        const int kd = lane < 3 ? lane : 0;
+        FseCell* const ktab = kd == T_LL ? sh.dll : (kd == T_OF ? sh.dof : sh.dml);
+        const u32* const ksym = kd == T_LL ? sh.symtab_ll : sh.symtab_ml;
+        if (lane < 3)
+            fse_build_lane(LDSP(FseCell, ktab), LDSP(i16, sh.ncount[kd]), kd == T_LL ? 36 : (kd == T_OF ? 29 : 53), kd == T_OF ? 5 : 6, kd,
+                           kd == T_OF ? (const ZPK_LDS u32*)nullptr : LDSP(u32, ksym), LDSP(u8, sh.spread[kd]), LDSP(u16, sh.nextc[kd]));
+    }
     __syncthreads();
 }
 
