@@ -394,81 +394,141 @@ __device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* s
     return (int)used;
 }
 
-// per-lane backward bit container for the Huffman streams (divergent: each lane its own stream)
-struct LaneBits {
+// per-lane backward bit container for the Huffman streams (divergent: each lane its own position).
+// Bit positions are 32-bit: a stream is at most 128 KiB.
+struct HufBits {
     const u8* start; const u8* rd_hi;
-    i64 pos;              // bits not yet consumed
-    i64 cb;               // container covers stream bits [cb*8, cb*8 + 128)
+    i32 cb;               // container covers stream bits [cb*8, cb*8 + 128)
     u64 c_lo, c_hi, pre;  // pre = the 8 bytes below c_lo, loaded one step ahead
 
-    __device__ __forceinline__ u64 fetch(i64 byte) const
+    __device__ __forceinline__ u64 fetch(i32 byte) const
     {
         const u8* a = start + byte;
         if (byte >= 0 && a + 8 <= rd_hi) return ld64(a);
         u64 v = 0;
-        for (int i = 0; i < 8; i++) { i64 bb = byte + i; if (bb >= 0 && start + bb < rd_hi) v |= (u64)start[bb] << (8 * i); }
+        #pragma unroll 1
+        for (int i = 0; i < 8; i++) { const i32 bb = byte + i; if (bb >= 0 && start + bb < rd_hi) v |= (u64)ld8(start + bb) << (8 * i); }
         return v;
     }
-    __device__ __forceinline__ void init(const u8* p, u64 size, const u8* hi, int hb)
+    __device__ __forceinline__ void seek(i32 pos)             // the next reads lie just below bit `pos`
     {
-        start = p; rd_hi = hi;
-        pos = (i64)(size - 1) * 8 + hb;
         cb = ((pos + 7) >> 3) - 16;
         c_lo = fetch(cb); c_hi = fetch(cb + 8); pre = fetch(cb - 8);
     }
     // bits [bp, bp+n), n <= 12; bp may be negative (zeros below 0)
-    __device__ __forceinline__ u32 peek(i64 bp, int n)
+    __device__ __forceinline__ u32 peek(i32 bp, int n)
     {
         while (bp < cb * 8) { c_hi = c_lo; c_lo = pre; cb -= 8; pre = fetch(cb - 8); }
-        int rel = (int)(bp - cb * 8);
-        u64 v = rel >= 64 ? c_hi >> (rel - 64) : (rel ? (c_lo >> rel) | (c_hi << (64 - rel)) : c_lo);
+        const int rel = bp - cb * 8;
+        const u64 v = rel >= 64 ? c_hi >> (rel - 64) : (c_lo >> rel) | ((c_hi << 1) << (63 - rel));
         return (u32)v & ((1u << n) - 1u);
     }
 };
 
-// decode `nstreams` (1 or 4) Huffman streams into lit[0..regen).  Whole wave; lanes 0..nstreams-1 work.
-__device__ inline bool huf_decode_streams(const ZstdShared& sh, const u8* p, u64 size, int nstreams, u8* lit, u64 regen,
-                                          const u8* rd_hi, u64 deadline, int lane)
+// One pass of one lane over its piece of a stream: decode from bit `entry` while the position is above `lo`.
+// MODE 0: count symbols, remember the positions visited in the first 128 bits below `top` (bit masks);
+// MODE 1: the same, but stop as soon as the position is one the previous pass visited — from there on the two
+//         passes are identical, so the previous count and exit are inherited; MODE 2: decode and store.
+struct HufRun { i32 exit; u32 n; u64 m0, m1; };
+template <int MODE>
+__device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, const u32 (&rk)[11], int mb, i32 entry, i32 lo, i32 top,
+                                          const HufRun& old, u8* out, u64 deadline, bool& bad)
 {
+    HufRun r; r.n = 0; r.m0 = 0; r.m1 = 0;
+    i32 pos = entry;
+    b.seek(pos);
+    bool merged = false;
+    while (pos > lo) {
+        const u32 rel = (u32)(top - pos);
+        if (MODE != 2 && rel < 128) {
+            const u64 bit = 1ull << (rel & 63);
+            if (MODE == 1 && ((rel < 64 ? old.m0 : old.m1) & bit)) { merged = true; break; }
+            if (rel < 64) r.m0 |= bit; else r.m1 |= bit;
+        }
+        if ((r.n & 4095u) == 4095u && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
+        const u32 idx = b.peek(pos - mb, mb);              // zeros below bit 0
+        u32 nb = (u32)mb;                                    // code length: max_bits + 1 - weight class, the class from the class starts
+        #pragma unroll
+        for (int w = 0; w < 11; w++) nb -= idx >= rk[w] ? 1u : 0u;
+        if (MODE == 2) st8(out + r.n, huf[idx]);
+        pos -= (i32)nb;
+        r.n++;
+    }
+    r.exit = pos;
+    if (MODE == 1 && merged) {
+        const u32 rel = (u32)(top - pos);
+        const u64 below0 = rel < 64 ? old.m0 & ((1ull << rel) - 1) : old.m0;
+        const u64 below1 = rel < 64 ? 0ull : old.m1 & ((1ull << (rel - 64)) - 1);
+        r.n += old.n - (u32)(__popcll(below0) + __popcll(below1));
+        r.m0 |= old.m0 & ~below0; r.m1 |= old.m1 & ~below1;
+        r.exit = old.exit;
+    }
+    return r;
+}
+
+// Decode `nstreams` (1 or 4) Huffman streams into lit[0..regen) with all 64 lanes: every stream is cut into 16
+// pieces by bit position and each lane decodes one.  Only the first piece starts on a code boundary; the others
+// start wherever the cut fell, which is wrong — but prefix codes re-synchronise within a few symbols, so a lane
+// re-decodes from its predecessor's exit only until it meets its own earlier trajectory (MODE 1), and the
+// exits converge to the true chain after a few cheap rounds (lane 0 of a stream is right from the start, so
+// the fixed point is the true decode).  A row prefix sum of the counts then places every piece, and one more
+// pass stores the symbols.  Two full passes with 64 lanes instead of one with 4.
+struct HufArgs { const u8* p; u64 size; int nstreams; u8* lit; u64 regen; const u8* rd_hi; u64 deadline; };
+__device__ __noinline__ bool huf_decode_streams(const ZPK_LDS u8* huf, const ZPK_LDS u32* rank, int mb, const HufArgs* a, int lane)
+{
+    const u8* const p = uni_ptr(a->p); const u64 size = uni64(a->size); const int nstreams = (int)uni((u32)a->nstreams);
+    u8* const lit = uni_ptr(a->lit); const u64 regen = uni64(a->regen); const u8* const rd_hi = uni_ptr(a->rd_hi);
+    const u64 deadline = uni64(a->deadline);
+    const int grp = lane >> 4, j = lane & 15;
     const u8* sp = p; u64 ssz = size; u8* out = lit; u64 cnt = regen;
-    bool bad = false;
     if (nstreams == 4) {
         if (size < 10) return false;
-        u64 s1 = uld16(p), s2 = uld16(p + 2), s3 = uld16(p + 4);
+        const u64 s1 = uld16(p), s2 = uld16(p + 2), s3 = uld16(p + 4);
         if (6 + s1 + s2 + s3 > size) return false;
-        u64 s4 = size - 6 - s1 - s2 - s3;
-        u64 seg = (regen + 3) / 4;
+        const u64 s4 = size - 6 - s1 - s2 - s3;
+        const u64 seg = (regen + 3) / 4;
         if (seg * 3 > regen) return false;
         const u8* q = p + 6;
-        lane0_guard();
-        if (lane == 0) { sp = q; ssz = s1; out = lit; cnt = seg; }
-        else if (lane == 1) { sp = q + s1; ssz = s2; out = lit + seg; cnt = seg; }
-        else if (lane == 2) { sp = q + s1 + s2; ssz = s3; out = lit + 2 * seg; cnt = seg; }
+        if (grp == 0) { sp = q; ssz = s1; out = lit; cnt = seg; }
+        else if (grp == 1) { sp = q + s1; ssz = s2; out = lit + seg; cnt = seg; }
+        else if (grp == 2) { sp = q + s1 + s2; ssz = s3; out = lit + 2 * seg; cnt = seg; }
         else { sp = q + s1 + s2 + s3; ssz = s4; out = lit + 3 * seg; cnt = regen - 3 * seg; }
     }
-    if (lane < nstreams) {
-        if (ssz == 0 || sp[ssz - 1] == 0) bad = true;
-        else {
-            const int mb = (int)sh.huf_max_bits;
-            // code length of a table index: max_bits + 1 - (weight class), the class by comparing against the
-            // (uniform) class starts — runs beside the symbol's LDS read instead of widening the table to 16 bits
-            u32 rk[11];
-            #pragma unroll
-            for (int w = 0; w < 11; w++) rk[w] = uni(sh.huf_rank[w + 2]);
-            LaneBits b; b.init(sp, ssz, rd_hi, highbit32(sp[ssz - 1]));
-            for (u64 i = 0; i < cnt; i++) {
-                if ((i & 4095) == 4095 && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
-                u32 idx = b.peek(b.pos - mb, mb);              // zeros below bit 0
-                const u32 sym = sh.huf[idx];
-                u32 nb = (u32)mb;
-                #pragma unroll
-                for (int w = 0; w < 11; w++) nb -= idx >= rk[w] ? 1u : 0u;
-                out[i] = (u8)sym;
-                b.pos -= (i64)nb;
-            }
-            if (b.pos != 0) bad = true;              // libzstd: BIT_endOfDStream required
-        }
+    const bool act = grp < nstreams;
+    bool bad = false;
+    i32 P = 0;
+    if (act) {
+        const u32 last = ssz ? (u32)ld8(sp + ssz - 1) : 0u;
+        if (last == 0 || ssz > (1u << 20)) bad = true;
+        else P = (i32)(ssz - 1) * 8 + highbit32(last);
     }
+    if (__ballot(bad) != 0) return false;
+    u32 rk[11];
+    #pragma unroll
+    for (int w = 0; w < 11; w++) rk[w] = uni(rank[w + 2]);
+    const i32 top = P - (i32)(((i64)P * j) >> 4), lo = P - (i32)(((i64)P * (j + 1)) >> 4);    // this lane's piece: positions (lo, top]
+    HufBits b; b.start = sp; b.rd_hi = rd_hi;
+    HufRun r; r.exit = top; r.n = 0; r.m0 = r.m1 = 0;
+    i32 entry = top;
+    if (act) r = huf_run<0>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad);
+    for (int iter = 0; iter < 17; iter++) {
+        i32 e = __shfl_up(r.exit, 1, 16);
+        if (j == 0) e = P;
+        const bool changed = act && e != entry;
+        if (__ballot(changed) == 0) break;
+        if (changed) { entry = e; r = huf_run<1>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad); }
+    }
+    // place the pieces: prefix sum of the symbol counts inside each 16-lane row
+    u32 x = act ? r.n : 0u;
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    const u32 total = (u32)__shfl((int)x, lane | 15, 64);
+    const i32 last_exit = __shfl(r.exit, lane | 15, 64);
+    if (act && ((u64)total != cnt || last_exit != 0)) bad = true;      // libzstd: exact symbol count and BIT_endOfDStream
+    if (__ballot(bad) != 0) return false;
+    if (act) (void)huf_run<2>(b, huf, rk, mb, entry, lo, top, r, out + (x - r.n), deadline, bad);
     return __ballot(bad) == 0;
 }
 
@@ -699,7 +759,8 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
             p += t; left -= (u64)t;
         } else if (!sh.huf_valid) return D_MALFORMED;
         __syncthreads();
-        if (!huf_decode_streams(sh, p, left, streams, lit_buf, regen, rd_hi, fs.wd->deadline, lane)) return D_MALFORMED;
+        HufArgs ha; ha.p = p; ha.size = left; ha.nstreams = streams; ha.lit = lit_buf; ha.regen = regen; ha.rd_hi = rd_hi; ha.deadline = fs.wd->deadline;
+        if (!huf_decode_streams(LDSP(u8, sh.huf), LDSP(u32, sh.huf_rank), (int)sh.huf_max_bits, &ha, lane)) return D_MALFORMED;
         wave_mem_fence();
         lit_size = regen; used = hl + csize;
     }
