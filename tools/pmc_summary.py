@@ -37,8 +37,14 @@ def summarise(d):
 if __name__ == "__main__":
     s = summarise(sys.argv[1])
     if "--json" in sys.argv:
+        doc = {"kernels": s, "source": "rocprofv3 --pmc, one pass per counter group (tools/pmc.sh)",
+               "units": "FETCH_SIZE/WRITE_SIZE converted KiB -> bytes, uncorrected; other counters raw, mean per dispatch"}
+        if "--entries" in sys.argv:
+            doc["entries_per_gpu"] = int(sys.argv[sys.argv.index("--entries") + 1])
+        if "--workload" in sys.argv:
+            doc["workload"] = sys.argv[sys.argv.index("--workload") + 1]
         with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
-            json.dump(s, fh, indent=1, sort_keys=True)
+            json.dump(doc, fh, indent=1, sort_keys=True)
     for k in sorted(s):
         print(k)
         for c in sorted(s[k]):
