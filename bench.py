@@ -207,7 +207,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                      # the CPU leg is reported at N=1 only
             cpu = cpu_baseline(batch, args.cpu_seconds, ncores)
         out = {
             "metric": "decompressed GiB/s over all entries; % HBM roofline" + (" [DIAGNOSTIC: hash skipped]" if args.skip_hash else ""),

@@ -1,15 +1,12 @@
-// lz4_wave.h — LZ4 frame + block decode, generic path: ONE WAVE PER ENTRY, output window in global
-// memory (L2-resident while hot).  Handles the whole LZ4 Frame format (any block size, linked or
-// independent blocks, stored blocks, optional checksums, skippable frames) and is the fallback for
-// frames the LDS-window fast path (lz4_lds.h) does not take.
+// lz4_wave.h — LZ4 frame + block decode: ONE WAVE PER ENTRY, output window = the entry's own output slot in
+// global memory.  Handles the whole LZ4 Frame format (any block size, linked or independent blocks, stored
+// blocks, optional header / block / content checksums, content size, skippable frames).
 //
 // Replaces the LZ4F_decompress loop of the reference (lib/zpack_read.c:414-439).
 //
-// Parsing is wave-uniform: the compressed stream is held as a 256-byte register window (one dword per
-// lane, one coalesced load per refill) and token / length / offset bytes are pulled out of it with
-// v_readlane, so the serial token chain never waits on memory.  Literal and match copies are done by
-// all 64 lanes (byte per lane, 64 bytes per instruction); overlapping matches (offset < length) read
-// the period [op-offset, op) with a modulo so that no lane depends on a byte written by the same copy.
+// Frame and block headers are read wave-uniformly; a compressed block is parsed lane-parallel out of an LDS
+// stage (speculative token-chain walks to a fixed point, see below) and executed 64 sequences at a time by
+// seq_exec_batch() (seq_exec.h).  The ByteWindow register window below serves the Zstandard bit readers.
 #pragma once
 #include "zpk_device.h"
 #include "xxh3_device.h"
@@ -17,7 +14,6 @@
 
 namespace zpk {
 
-// 256-byte sliding register window over a read-only byte stream
 // the window word of one lane: bytes [a, a+4) clipped to [lo, hi).  Out of line on purpose: the bit readers
 // inline into dozens of call sites, and this rarely-taken body (once per ~240 stream bytes) was most of the
 // Zstandard kernel's code size.
@@ -30,6 +26,7 @@ __device__ __noinline__ u32 window_word(const u8* a, const u8* lo, const u8* hi)
     return v;
 }
 
+// 256-byte sliding register window over a read-only byte stream
 struct ByteWindow {
     u32 w;              // lane l holds bytes [base + 4l, base + 4l + 4)
     const u8* base;     // 4-byte aligned, uniform
@@ -59,11 +56,12 @@ struct DecodeOut { int rc; u64 produced; };
 // dependent scalar chain; measured).  Instead the block is taken in chunks of 64 segments x LZ4W_SEG
 // bytes staged in LDS: every lane walks its own segment from a guessed entry, then re-walks from its
 // predecessor's exit until no entry changes (LZ4 chains re-synchronise within a few tokens; lane 0's
-// entry is the true chain position, so the fixed point is the true chain).  A wave prefix sum numbers
-// the chunk's sequences, one more walk writes each sequence's token position into a u16 record array,
-// and the chunk is then executed 64 consecutive sequences at a time: lane k re-reads token k's fields
-// from LDS and seq_exec_batch() (seq_exec.h) does the copies in HBM/L2 with in-register dependency
-// masks.  LDS per wave: one 4.3 KiB chunk (68-byte segments measured best: 331 GiB/s vs 320 at 84, 303 at 108).
+// entry is the true chain position, so the fixed point is the true chain).  A DPP prefix sum numbers
+// the chunk's sequences, every lane lists its token positions (the set bits of its visited mask) in a u16
+// LDS list, and the chunk is then executed 64 consecutive sequences at a time: lane k re-reads token k's
+// fields from LDS and seq_exec_batch() (seq_exec.h) does the copies, assembling the batch in the part of
+// the stage the chunk has already consumed when it fits.  LDS per wave: a 3.9 KiB stage (60-byte segments;
+// 68 measured equal, 84/108 slower) + the 1.1 KiB list.
 #ifndef LZ4W_SEG
 #define LZ4W_SEG 60u                            // 15 dwords: odd, so 64 lanes spread over all LDS banks; <= 64 for the visited mask
 #endif
