@@ -52,6 +52,9 @@ def cpu_baseline(batch, seconds, threads):
                         sample="zpack_read_file (decode + XXH3 verify) of the compiled reference over the first %d entries of "
                                "the same archive, %d thread(s), looped for %.1f s (%.2f GiB decoded)" %
                                (sample, threads, out[1], out[0] / 2**30))
+        why = "reference driver rc=%d errors=%d; " % (rc, int(out[2]))
+    else:
+        why = "oracle/_ref not built; "
     from tests._libs import oracle
     o = oracle()
     arc = batch.archive.tobytes() if batch.archive.size < (1 << 31) else None
@@ -66,7 +69,7 @@ def cpu_baseline(batch, seconds, threads):
         i += 1
     dt = time.time() - t0
     return dict(value=done / dt / 2**30, unit="GiB/s", cores=1, kind="port",
-                sample="oracle/liboracle.so entry_decode over %d entries, 1 thread, %.1f s" % (i, dt))
+                sample=why + "oracle/liboracle.so entry_decode over %d entries, 1 thread, %.1f s" % (i, dt))
 
 
 def main():

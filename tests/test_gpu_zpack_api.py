@@ -177,7 +177,7 @@ def test_batch_write_then_batch_read_roundtrip(Z, method, level):
     want = [("f%03d" % i, dg.fill(i % 4, 77, i, n).tobytes()) for i, n in enumerate(sizes)]
     arc = Z.write_archive(want, method, level)
     _decode_all_with_checkers(arc, want)
-    if method == METHOD_LZ4:                                     # the device compressor must actually compress text / records / runs
+    if method in (METHOD_LZ4, METHOD_ZSTD):                      # the device compressors must actually compress text / records / runs
         ents = zpk.parse(arc)
         for e, (n, d) in zip(ents, want):
             if len(d) >= 4095 and int(n[1:]) % 4 != dg.RANDOM:

@@ -248,6 +248,7 @@ struct zpk_codec {
     void* d_desc = nullptr;      u64 desc_cap = 0;
     void* d_res = nullptr;       u64 res_cap = 0;
     u64* d_dbg = nullptr;        u64 dbg_cap = 0;
+    u64* d_seq = nullptr;        u64 seq_cap = 0;      // encoder: sequence lists, one per workgroup
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t kev[ZPK_K_COUNT][2] = {};
     int profiling = 0;
@@ -311,6 +312,7 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     (void)hipFree(c->d_counters); (void)hipFree(c->d_lists); (void)hipFree(c->d_lit);
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
+    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
