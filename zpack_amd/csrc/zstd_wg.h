@@ -295,7 +295,6 @@ __device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
     }
     __syncthreads();
     if (!ok_flag) return false;
-    const int mb = (int)sh.huf_max_bits;
     // fill: symbols of one weight take consecutive ranges in natural order -> serial over symbols per
     // weight for the range starts (lane 0, running starts in huf_cnt), then all lanes fill the ranges
     if (lane < 16) sh.huf_cnt[lane] = sh.huf_rank[lane];
