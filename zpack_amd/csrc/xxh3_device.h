@@ -184,7 +184,7 @@ struct Xxh3Wave {
 
 // XXH3_64bits(p, len) computed by one full wave (all 64 lanes must call; result uniform).
 // `p` may have any alignment.
-__device__ inline u64 xxh3_64_wave(const u8* p, u64 len, int lane)
+__device__ __forceinline__ u64 xxh3_64_wave(const u8* p, u64 len, int lane)
 {
     if (len <= 240) {
         u64 h = 0;
