@@ -197,13 +197,16 @@ struct SeqBatch {
 // k's dependency set is a valid (superset) set for j, and if k's source sits inside m's, so does j's.
 // (delta, need, inside) of k are read before k itself jumps in the same round, which keeps the triple
 // consistent; the depth of every chain halves per round.
+// S = i32 when every position and offset of the batch fits 31 bits (always, for LZ4): one-instruction compares and
+// single-dword shuffles instead of 64-bit pairs; S = i64 otherwise.
+template <typename S>
 __device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_me, u32 off, u32 need_len, u64 pending, int lane,
                                                 i64& src_out, SeqStats& stt)
 {
     (void)stt;
-    i64 src = (i64)r_ms - (i64)off;
+    S src = (S)r_ms - (S)off;
     u64 need = 0;
-    const i64 send0 = src + (i64)need_len;
+    const S send0 = src + (S)need_len;
     const bool reads_batch = has_match && send0 > 0;
     if (pending && __ballot(reads_batch) != 0) {
         // which earlier matches of the batch does [src, send) touch?  Output ranges are sorted by lane, so two
@@ -214,8 +217,8 @@ __device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_
         for (int step = 32; step >= 1; step >>= 1) {
             const u32 a = (u32)__shfl((int)r_me, klo + step - 1, 64);
             const u32 b = (u32)__shfl((int)r_ms, khi + step - 1, 64);
-            if ((i64)a <= src) klo += step;
-            if ((i64)b < send0) khi += step;
+            if ((S)a <= src) klo += step;
+            if ((S)b < send0) khi += step;
         }
         if (reads_batch && klo < khi) {
             if (khi > lane) khi = lane;
@@ -227,21 +230,22 @@ __device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_
             const int probe = inside < 0 ? lane : inside;
             const u32 kms = (u32)__shfl((int)r_ms, probe, 64);
             const u32 knl = (u32)__shfl((int)need_len, probe, 64);
-            if (inside >= 0 && !((i64)kms <= src && send0 <= (i64)kms + (i64)knl)) inside = -1;
+            if (inside >= 0 && !((S)kms <= src && send0 <= (S)kms + (S)knl)) inside = -1;
         }
         #pragma unroll 1
         for (int round = 0; round < SEQ_DEP_ROUNDS; round++) {
             if (__ballot(inside >= 0) == 0) break;
             SEQ_STAT(stt.redirects += (u32)__popcll(__ballot(inside >= 0)));
             const int probe = inside < 0 ? lane : inside;
-            const i64 my_delta = (i64)r_ms - src;
-            const u32 dlo = (u32)__shfl((int)(u32)(u64)my_delta, probe, 64), dhi = (u32)__shfl((int)(u32)((u64)my_delta >> 32), probe, 64);
+            const S my_delta = (S)r_ms - src;
+            const u32 dlo = (u32)__shfl((int)(u32)(u64)(i64)my_delta, probe, 64);
+            const u32 dhi = sizeof(S) == 8 ? (u32)__shfl((int)(u32)((u64)(i64)my_delta >> 32), probe, 64) : 0u;
             const u32 nlo = (u32)__shfl((int)(u32)need, probe, 64), nhi = (u32)__shfl((int)(u32)(need >> 32), probe, 64);
             const int kin = __shfl(inside, probe, 64);
-            if (inside >= 0) { src -= (i64)(((u64)dhi << 32) | dlo); need = ((u64)nhi << 32) | nlo; inside = kin; }
+            if (inside >= 0) { src -= sizeof(S) == 8 ? (S)(i64)(((u64)dhi << 32) | dlo) : (S)(i32)dlo; need = ((u64)nhi << 32) | nlo; inside = kin; }
         }
     }
-    src_out = src;
+    src_out = (i64)src;
     return need;
 }
 
@@ -276,7 +280,9 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     const u32 r_ms = (u32)(ms - op), r_me = r_ms + ml;           // this lane's match output [r_ms, r_me)
     const u32 need_len = ml < q.off ? ml : q.off;                 // bytes not produced by the match itself
     i64 src;
-    const u64 need = seq_dependencies(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt);
+    const bool narrow = total < (1u << 30) && __ballot(has_match && q.off >= (1u << 30)) == 0;     // uniform
+    const u64 need = narrow ? seq_dependencies<i32>(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt)
+                            : seq_dependencies<i64>(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt);
     const u8* const srcp = op + src;                               // (possibly re-pointed) source of the first need_len bytes
     const bool self_overlap = ml > need_len;                       // offset < length: the match feeds itself
     const bool coop = has_match && (ml > SEQ_OWN_MAX || self_overlap);
