@@ -139,9 +139,15 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
 /* per-kernel timing of decode batches: when enabled, every decode batch brackets each of its kernels
  * with HIP events on the launch stream; zpk_codec_kernel_ms then returns the duration of kernel
  * `which` (ZPK_K_*) in the most recent batch (synchronises on that batch). */
-enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2, ZPK_K_ZSTD = 3, ZPK_K_COUNT = 4 };
+enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2, ZPK_K_ZSTD = 3, ZPK_K_ZSTD_FSE = 4, ZPK_K_COUNT = 5 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
+/* counters of the most recent decode batch (synchronises): out[0..2] = entries on the stored / zstd / lz4 work
+ * lists, out[3] = Zstandard entries finished on pre-decoded sequences (two-stage path), out[4] = by the fused decoder,
+ * out[5], out[6] = entries / waves the pre-decode kernel gave up on (watchdog; expected 0) */
+int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8]);
 int zpk_codec_debug_read(zpk_codec* c, void* host, uint64_t bytes);   /* developer aid: phase timing words */
+/* developer aid: read back the Zstandard pre-decode arena (what 0) / per-entry marks (what 1) of the last batch */
+int zpk_codec_debug_fetch(zpk_codec* c, int what, uint64_t offset, void* host, uint64_t bytes);
 int zpk_codec_kernel_ms(zpk_codec* c, int which, float* ms);
 int zpk_codec_timer_start(zpk_codec* c, void* stream);
 int zpk_codec_timer_stop(zpk_codec* c, void* stream, float* elapsed_ms);   /* synchronises the stop event */

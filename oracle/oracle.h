@@ -93,6 +93,10 @@ typedef struct orc_zstd_stats_s {
     uint32_t single_segment, has_fcs, has_checksum;
 } orc_zstd_stats;
 const orc_zstd_stats* orc_zstd_last_stats(void);
+/* trace of the sequences orc_zstd_decode executes, packed offset | match length << 29 | literal length << 47 (the
+ * layout of zpack_amd/csrc/zstd_fse4.h), into buf[0..cap); NULL switches it off.  Count = sequences seen. */
+void orc_zstd_trace(uint64_t* buf, size_t cap);
+size_t orc_zstd_trace_count(void);
 
 /* ---- encoders (replace LZ4F_compressBegin/Update/End, zpack_write.c:204-210, and
  *      ZSTD_compressCCtx, zpack_write.c:179).  Compressed bytes are NOT pinned by any reference

@@ -385,6 +385,13 @@ static int decode_literals(frame_ctx* c, const uint8_t* src, size_t size, size_t
 }
 
 /* decode + execute the sequences of one compressed block; `frame_out` = bytes of this frame already in dst */
+/* optional trace of the decoded sequences (offset | match length << 29 | literal length << 47), for the tests that
+ * check the GPU's FSE pre-decode kernel (zpack_amd/csrc/zstd_fse4.h) sequence by sequence */
+static uint64_t* g_trace; static size_t g_trace_cap, g_trace_n; static int64_t* g_trace_bits;
+void orc_zstd_trace_bits(int64_t* buf) { g_trace_bits = buf; }
+void orc_zstd_trace(uint64_t* buf, size_t cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+size_t orc_zstd_trace_count(void) { return g_trace_n; }
+
 static int decode_block(frame_ctx* c, const uint8_t* src, size_t size, uint8_t* dst, size_t dst_cap,
                         size_t frame_out, size_t* produced)
 {
@@ -464,6 +471,10 @@ static int decode_block(frame_ctx* c, const uint8_t* src, size_t size, uint8_t* 
             sml = c->ml.base[sml] + (uint32_t)bwd_read(&b, c->ml.nbits[sml]);
             sof = c->of.base[sof] + (uint32_t)bwd_read(&b, c->of.nbits[sof]);
 
+            if (g_trace) {
+                if (g_trace_n < g_trace_cap) { g_trace[g_trace_n] = offset | (mlen << 29) | (llen << 47); if (g_trace_bits) g_trace_bits[g_trace_n] = (int64_t)b.bits; }
+                g_trace_n++;
+            }
             if (llen + mlen > dst_cap - op) return E_DST_FULL;
             if (llen > lit_size - lit_pos) return E_CORRUPT;
             memcpy(dst + op, c->lit + lit_pos, (size_t)llen);

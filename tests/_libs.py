@@ -90,6 +90,24 @@ class Oracle:
     def zstd_decode(self, data, cap):
         return self._dec(self.lib.orc_zstd_decode, data, cap)
 
+    def zstd_sequences(self, data, cap, max_seq=1 << 22):
+        """Sequences orc_zstd_decode executes for this frame stream, packed like zpack_amd/csrc/zstd_fse4.h."""
+        import numpy as np
+        buf = np.zeros(max_seq, dtype=np.uint64)
+        self.last_trace_bits = np.zeros(max_seq, dtype=np.int64)
+        self.lib.orc_zstd_trace_bits.argtypes = [C.c_void_p]
+        self.lib.orc_zstd_trace_bits(self.last_trace_bits.ctypes.data)
+        self.lib.orc_zstd_trace.argtypes = [C.c_void_p, C.c_size_t]
+        self.lib.orc_zstd_trace_count.restype = C.c_size_t
+        self.lib.orc_zstd_trace(buf.ctypes.data, max_seq)
+        try:
+            rc, out = self.zstd_decode(data, cap)
+            n = int(self.lib.orc_zstd_trace_count())
+        finally:
+            self.lib.orc_zstd_trace(None, 0)
+            self.lib.orc_zstd_trace_bits(None)
+        return rc, buf[:min(n, max_seq)].copy()
+
     def zstd_stats(self):
         return self.lib.orc_zstd_last_stats().contents
 

@@ -168,3 +168,35 @@ def test_device_batch_vs_oracle(codec, method, level, size, n):
                                           int(d["expect_hash"]), int(d["method"]), int(d["dst_capacity"]))
         assert rc == 0
         assert out[int(d["dst_offset"]):int(d["dst_offset"] + d["uncomp_size"])].tobytes() == want, i
+
+
+@pytest.mark.parametrize("size,level,n", [(262144, 3, 64), (1 << 20, 1, 24), (5000, 3, 200)])
+def test_zstd_two_stage_path(codec, size, level, n):
+    """The Zstandard batch goes FSE pre-decode (k_zstd_fse, four streams per wave) -> literals + execution.  With the
+    XXH3 verify switched off nothing can paper over a wrong pre-decoded sequence: every byte of every entry must
+    equal the oracle's, and the counters must show that the entries really finished on the two-stage path."""
+    import torch
+    o = oracle()
+    b = dg.Batch(n, size, method=dg.ZSTD, level=level, seed=11)
+    desc, total = zpack_amd.decode_descs_from_batch(b, flags=zpack_amd.DF_SKIP_HASH)
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(b.archive).to(dev)
+    dst = torch.zeros(total, dtype=torch.uint8, device=dev)
+    ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    dres = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+    codec.decode_batch_device(src, ddesc, n, dst, dres)
+    torch.cuda.synchronize()
+    st = codec.decode_stats()
+    res = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)
+    out = dst.cpu().numpy()
+    assert (res["status"] == 0).all(), res[res["status"] != 0][:5]
+    assert np.array_equal(res["produced"], b.uncomp_sizes)
+    arc = b.archive.tobytes()
+    for i in range(n):
+        d = desc[i]
+        rc, want, got, h = o.entry_decode(arc, int(d["src_offset"]), int(d["comp_size"]), int(d["uncomp_size"]),
+                                          int(d["expect_hash"]), int(d["method"]), int(d["dst_capacity"]))
+        assert rc == 0
+        assert out[int(d["dst_offset"]):int(d["dst_offset"] + d["uncomp_size"])].tobytes() == want, i
+    assert st["zstd"] == n and st["zstd_two_stage"] + st["zstd_fused"] == n, st
+    assert st["zstd_two_stage"] >= (3 * n) // 4, st

@@ -16,7 +16,7 @@ ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
 
 METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
-K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD = 0, 1, 2, 3
+K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE = 0, 1, 2, 3, 4
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
 DECODE_DESC = np.dtype([("src_offset", "<u8"), ("comp_size", "<u8"), ("uncomp_size", "<u8"), ("expect_hash", "<u8"),
@@ -67,6 +67,8 @@ def lib():
         L.zpk_codec_set_profiling.argtypes = [vp, C.c_int]
         L.zpk_codec_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
         L.zpk_codec_debug_read.argtypes = [vp, vp, u64]
+        L.zpk_codec_debug_fetch.argtypes = [vp, C.c_int, u64, vp, u64]
+        L.zpk_codec_decode_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.zpk_codec_timer_start.argtypes = [vp, vp]
         L.zpk_codec_timer_stop.argtypes = [vp, vp, C.POINTER(C.c_float)]
         _lib = L
@@ -126,6 +128,17 @@ class Codec:
         ms = C.c_float(0)
         self._chk(self.L.zpk_codec_kernel_ms(self.h, which, C.byref(ms)), "kernel_ms")
         return ms.value
+
+    def decode_stats(self):
+        """Counters of the last decode batch: entries per method and how the Zstandard ones were finished."""
+        a = (C.c_uint32 * 8)()
+        self._chk(self.L.zpk_codec_decode_stats(self.h, a), "decode_stats")
+        return dict(stored=a[0], zstd=a[1], lz4=a[2], zstd_two_stage=a[3], zstd_fused=a[4], fse_watchdog=a[5], fse_budget=a[6])
+
+    def debug_fetch(self, what, offset, count, dtype):
+        a = np.zeros(count, dtype=dtype)
+        self._chk(self.L.zpk_codec_debug_fetch(self.h, what, offset, a.ctypes.data, a.nbytes), "debug_fetch")
+        return a
 
     def debug_read(self, n):
         a = np.zeros((n, 8), dtype=np.uint64)

@@ -41,6 +41,8 @@ def build_codec(force=False, verbose=False):
            "-Wno-unused-function", "-o", CODEC_SO, os.path.join(CSRC, "zpk_codec.hip")]
     if os.environ.get("ZPK_STATS"):          # developer build: per-phase cycle counters in the decode kernels
         cmd.insert(1, "-DZPK_STATS=1")
+    for d in os.environ.get("ZPK_DEFINES", "").split():      # developer build: A/B variants (-D names)
+        cmd.insert(1, "-D" + d)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

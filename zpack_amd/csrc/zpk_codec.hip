@@ -20,11 +20,14 @@
 #include "xxh3_device.h"
 #include "lz4_wave.h"
 #include "zstd_wg.h"
+#include "zstd_fse4.h"
 
 using namespace zpk;
 
 // counters layout (u32): [0..3] count per work list, [4..7] dequeue head per list
 enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4, N_LISTS = 3 };
+// [8] dequeue head of k_zstd_fse, [9] Zstandard entries finished on pre-decoded sequences, [10] finished by the fused decoder
+enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10 };
 
 // ------------------------------------------------------------------------------------ kernels
 
@@ -191,7 +194,8 @@ __global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, 
 __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                           u8* dst, zpk_decode_result* __restrict__ res,
                                                           const u32* __restrict__ list, u32* __restrict__ counters,
-                                                          u8* __restrict__ lit_scratch, u64* __restrict__ dbg)
+                                                          u8* __restrict__ lit_scratch, u64* __restrict__ dbg,
+                                                          const u64* __restrict__ arena, const u32* __restrict__ zstate)
 {
     const int lane = lane_id();
     __shared__ ZstdShared sh;
@@ -204,21 +208,48 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restric
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
-        Watchdog wd; wd.arm();
+        // Pass 0 runs on the sequences k_zstd_fse left in the arena (zstd_fse4.h) when it marked the entry; whenever that
+        // pass does not end in a verified entry, pass 1 decodes the entry in full, so the verdict is always the fused
+        // decoder's.
+        const bool marked = zstate != nullptr && uni(zstate[e]) == 1u;
+        const u64* const pre = arena + (((u64)d.dst_offset + 7) >> 3);
+        #pragma unroll 1
+        for (int pass = marked ? 0 : 1; pass < 2; pass++) {
+            Watchdog wd; wd.arm();
 #ifdef ZPK_STATS
-        ZstdStats zs = {};
-        const u64 t_all = SEQ_T();
-        DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, &zs);
-        if (dbg && lane == 0) {
-            u64* g = dbg + (u64)e * 8;
-            g[0] = zs.t_lit; g[1] = zs.t_tab; g[2] = zs.t_fse; g[3] = zs.t_exec; g[4] = zs.nseq; g[5] = zs.nblk; g[6] = SEQ_T() - t_all; g[7] = 0;
-        }
+            ZstdStats zs = {};
+            const u64 t_all = SEQ_T();
+            DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, &zs, pass == 0 ? pre : nullptr);
+            if (dbg && lane == 0) {
+                u64* g = dbg + (u64)e * 8;
+                g[0] = zs.t_lit; g[1] = zs.t_tab; g[2] = zs.t_fse; g[3] = zs.t_exec; g[4] = zs.nseq; g[5] = zs.nblk; g[6] = SEQ_T() - t_all; g[7] = (u64)pass;
+            }
 #else
-        (void)dbg;
-        DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane);
+            (void)dbg;
+            DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, nullptr, pass == 0 ? pre : nullptr);
 #endif
-        int status = o.rc == D_OK ? R_OK : R_DECOMPRESS_FAILED;               // lib/zpack_read.c:384-388
-        finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
+            int status = o.rc == D_OK ? R_OK : R_DECOMPRESS_FAILED;               // lib/zpack_read.c:384-388
+            u64 h = 0;
+            lane0_guard();
+            if (status == R_OK && !(d.flags & ZPK_DF_SKIP_HASH)) {
+                wave_mem_fence();
+                h = xxh3_64_wave(out, d.uncomp_size, lane);                        // lib/zpack_read.c:466
+                if (h != d.expect_hash) status = R_FILE_HASH_MISMATCH;             // :467-468
+            }
+            if (pass == 0 && status != R_OK) {
+                lane0_guard();
+                if (lane == 0) { atomicAdd(&counters[14], 1u); counters[15] = ((u32)status << 16) | ((u32)(-o.rc) & 0xFFFFu); }
+                lane0_guard();
+                continue;
+            }
+            lane0_guard();
+            if (lane == 0) {
+                zpk_decode_result r; r.status = status; r.detail = wd.fired ? 0xDEADu : (u32)(-o.rc); r.produced = o.produced; r.hash = h;
+                res[e] = r;
+                atomicAdd(&counters[pass == 0 ? C_ZSTD_TWO_STAGE : C_ZSTD_FUSED], 1u);
+            }
+            break;
+        }
     }
 }
 
@@ -249,6 +280,9 @@ struct zpk_codec {
     void* d_res = nullptr;       u64 res_cap = 0;
     u64* d_dbg = nullptr;        u64 dbg_cap = 0;
     u64* d_seq = nullptr;        u64 seq_cap = 0;      // encoder: sequence lists, one per workgroup
+    u64* d_zarena = nullptr;     u64 zarena_cap = 0;   // decoder: pre-decoded Zstandard sequences, laid out like dst (zstd_fse4.h)
+    u64* d_zdbg = nullptr;       u64 zdbg_cap = 0;     // developer aid (ZPK_ZF_DEBUG=1): per-sequence stream positions
+    u32* d_zstate = nullptr;     u64 zstate_cap = 0;   // decoder: per entry, 1 = its sequences are in the arena
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t kev[ZPK_K_COUNT][2] = {};
     int profiling = 0;
@@ -312,7 +346,7 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     (void)hipFree(c->d_counters); (void)hipFree(c->d_lists); (void)hipFree(c->d_lit);
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
-    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq);
+    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_zdbg);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
@@ -362,9 +396,29 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
                        c->d_lists + L_LZ4 * stride, c->d_counters, c->d_dbg, want_dbg == 2 ? 1 : 0);
     ZPK_KEV(ZPK_K_LZ4, 1);
     ZPK_TRACE_STEP("k_lz4_wave");
+    // Zstandard in two stages: the FSE sequence streams four per wave into an arena laid out like dst (8 bytes per
+    // sequence: room for one sequence per 8 output bytes; entries that need more stay with the fused decoder), then
+    // literals + execution + checksum.  Without the arena (allocation refused, ZPK_ZSTD_FUSED=1) k_zstd does it all.
+    static const int fused_only = getenv("ZPK_ZSTD_FUSED") ? atoi(getenv("ZPK_ZSTD_FUSED")) : 0;
+    bool two_stage = !fused_only && dst_size >= 64;
+    if (two_stage && (grow(c, (void**)&c->d_zarena, &c->zarena_cap, dst_size + 64) != ZPK_OK ||
+                      grow(c, (void**)&c->d_zstate, &c->zstate_cap, n * sizeof(u32)) != ZPK_OK)) { two_stage = false; c->err[0] = 0; }
+    u64* zdbg = nullptr;
+    static const int zf_debug = getenv("ZPK_ZF_DEBUG") ? atoi(getenv("ZPK_ZF_DEBUG")) : 0;
+    if (zf_debug && two_stage && grow(c, (void**)&c->d_zdbg, &c->zdbg_cap, dst_size + 64) == ZPK_OK) zdbg = c->d_zdbg;
+    ZPK_KEV(ZPK_K_ZSTD_FSE, 0);
+    if (!(skip & 4) && two_stage) {
+        HIPCHK(c, hipMemsetAsync(c->d_zstate, 0, n * sizeof(u32), st));          // entries k_zstd_fse never reaches stay unmarked
+        const u64 zwaves = (n + ZF_ROWS - 1) / ZF_ROWS;
+        hipLaunchKernelGGL(k_zstd_fse, dim3((u32)(zwaves < ZF_GRID_MAX ? zwaves : ZF_GRID_MAX)), dim3(64), 0, st, src, desc,
+                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_zarena, c->d_zstate, zdbg);
+    }
+    ZPK_KEV(ZPK_K_ZSTD_FSE, 1);
+    ZPK_TRACE_STEP("k_zstd_fse");
     ZPK_KEV(ZPK_K_ZSTD, 0);
     if (!(skip & 4)) hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
-                       c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_dbg);
+                       c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_dbg,
+                       two_stage ? c->d_zarena : (const u64*)nullptr, two_stage ? c->d_zstate : (const u32*)nullptr);
     ZPK_KEV(ZPK_K_ZSTD, 1);
     ZPK_TRACE_STEP("k_zstd");
     if (trace == 2) {
@@ -491,6 +545,35 @@ int zpk_codec_debug_read(zpk_codec* c, void* host, uint64_t bytes)
     if (!c || !c->d_dbg || bytes > c->dbg_cap) return ZPK_E_INVALID;
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(host, c->d_dbg, bytes, hipMemcpyDeviceToHost));
+    return ZPK_OK;
+}
+
+// counters of the most recent decode batch (synchronises the device): out[0..2] = entries per work list
+// (none, zstd, lz4), out[3] = Zstandard entries finished on pre-decoded sequences, out[4] = by the fused decoder
+int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8])
+{
+    if (!c || !out) return ZPK_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    u32 h[16];
+    HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[L_NONE]; out[1] = h[L_ZSTD]; out[2] = h[L_LZ4]; out[3] = h[C_ZSTD_TWO_STAGE]; out[4] = h[C_ZSTD_FUSED];
+    out[5] = h[ZF_WATCHDOG_WORD]; out[6] = h[ZF_WATCHDOG_WORD + 1]; out[7] = h[13];
+    if (getenv("ZPK_TRACE")) fprintf(stderr, "[zpk] fse marked %u, pass-0 failures %u, last failure status/rc %08x\n", h[13], h[14], h[15]);
+    return ZPK_OK;
+}
+
+// developer aid: read back part of the Zstandard sequence arena (what = 0, byte offset = the entry's dst_offset
+// rounded up to 8) or of the per-entry marks (what = 1, u32 per entry) of the most recent decode batch
+int zpk_codec_debug_fetch(zpk_codec* c, int what, uint64_t offset, void* host, uint64_t bytes)
+{
+    if (!c || !host) return ZPK_E_INVALID;
+    const u8* base = what == 0 ? (const u8*)c->d_zarena : (what == 1 ? (const u8*)c->d_zstate : (const u8*)c->d_zdbg);
+    const u64 cap = what == 0 ? c->zarena_cap : (what == 1 ? c->zstate_cap : c->zdbg_cap);
+    if (!base || offset > cap || bytes > cap - offset) return ZPK_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(host, base + offset, bytes, hipMemcpyDeviceToHost));
     return ZPK_OK;
 }
 

@@ -1,0 +1,504 @@
+// zstd_fse4.h — Zstandard sequences pre-decode: FOUR FSE streams per wave, one per 16-lane DPP row.
+//
+// Why.  The sequences section of a block (RFC 8878 3.1.1.3.2) is a serial state machine: ~700 cycles of dependent
+// work per sequence for a wave, and the number of streams a CU can have in flight is bounded by the LDS their
+// three decode tables take (5 KiB).  The fused kernel (zstd_wg.h) spends a whole wave, 168 VGPRs and 13 KiB of LDS
+// on ONE stream (12 per CU) and 77 % of a text entry's time in that chain.  Here a stream costs a quarter of a
+// wave and 6 KiB (tables + a 512-byte bitstream ring + construction scratch): 24 streams per CU, and a wave
+// instruction advances four chains at once.
+//
+// What.  k_zstd_fse walks every frame and block of an entry exactly like zstd_decode_wave, skips the literals
+// sections, builds the block's LL/OF/ML tables, decodes the sequences (repeat offsets resolved) and writes them
+// packed into 8 bytes each to the batch's sequence arena (HBM), in stream order.  k_zstd then runs the entry with
+// the sequences already decoded (literals + execution + checksum only).  ANYTHING unusual — a malformed header,
+// a length that does not fit the packing, an arena region that is too small — just leaves the entry unmarked and
+// k_zstd decodes it in full; and when a pre-decoded run fails or its XXH3 does not match, k_zstd repeats the
+// entry in full as well, so the verdict of every entry is the fused decoder's (the reference's, zpack_read.c:380).
+//
+// Rows are independent state machines inside one wave: a persistent loop in which every row that is in the
+// middle of a block advances by one sequence, and rows that are between blocks run the (divergent, rare)
+// header / table-construction code first.  All per-row values are row-uniform VGPRs — nothing here may use
+// readfirstlane.
+#pragma once
+#include "zstd_wg.h"
+
+namespace zpk {
+
+#define ZF_ROWS 4
+#define ZF_RING 512u                               // two 256-byte chunks of the backward bitstream
+#define ZF_SEQ_OFF_BITS 29                         // packed sequence: offset | match length << 29 | literal length << 47
+#define ZF_SEQ_ML_BITS 18
+#define ZF_SEQ_LL_BITS 17
+#define ZF_GRID_MAX (256u * 6u)                    // 6 workgroups per CU (LDS: 25.6 KiB each)
+#define ZF_HEAD 8                                  // counters[] word used as this kernel's dequeue head
+#define ZF_WATCHDOG_WORD 11                        // counters[11]: entries given up by the row watchdog, [12]: header-loop budget hits
+#define ZF_COUNT_WORD 1                            // counters[] word holding the length of the Zstandard work list (L_ZSTD)
+
+struct alignas(16) ZfRow {
+    FseCell ll[512], ml[512], of[256];
+    u8  ring[ZF_RING + 16];                        // + mirror of the first 8 bytes (reads are 8 bytes wide at any byte offset)
+    i16 ncount[3][64];                             // normalized counts, then (in place) the per-symbol next-state counters
+    u64 seqbuf[16];                                // 16 packed sequences: the row flushes them as one 128-byte store
+};
+struct alignas(16) ZfShared {
+    ZfRow row[ZF_ROWS];
+    FseCell dll[64], dml[64], dof[32];             // predefined distributions
+    u32 symtab_ll[36], symtab_ml[54];              // baseline | extra bits << 24
+    u32 pad[2];
+};
+
+// Decode table from normalized counts, by ONE lane, in place: the spread symbols are parked in the table itself
+// and the next-state counters overwrite the counts.  Same construction as fse_build_lane (zstd_wg.h).
+__device__ __noinline__ bool fse_build_inplace(ZPK_LDS FseCell* tab, ZPK_LDS i16* nc, int nsym, int al, int kind, const ZPK_LDS u32* symtab)
+{
+    const int size = 1 << al;
+    int high = size;
+    #pragma unroll 1
+    for (int s = 0; s < nsym; s++)
+        if (nc[s] == -1) tab[--high] = (u32)s;
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    #pragma unroll 1
+    for (int s = 0; s < nsym; s++) {
+        const int f = nc[s];
+        if (f <= 0) continue;
+        #pragma unroll 1
+        for (int i = 0; i < f; i++) {
+            if (pos < high) tab[pos] = (u32)s;                  // positions >= high belong to the -1 symbols: skipped below
+            do { pos = (pos + step) & mask; } while (pos >= high);
+        }
+    }
+    if (pos != 0) return false;
+    #pragma unroll 1
+    for (int s = 0; s < nsym; s++) { const int f = nc[s]; nc[s] = (i16)(f == -1 ? 1 : (f > 0 ? f : 0)); }
+    #pragma unroll 1
+    for (int i = 0; i < size; i++) {
+        const u32 s = tab[i];
+        const u32 n = (u32)(u16)nc[s];
+        nc[s] = (i16)(n + 1);
+        const u32 nb = (u32)al - (u32)highbit32(n);
+        const u32 add = symtab ? symtab[s] >> 24 : (kind == T_OF ? s : 0u);
+        tab[i] = fse_cell((n << nb) - (u32)size, nb, add, s);
+    }
+    return true;
+}
+
+// 16 bytes at stream offset `byte` of [bs, bs+size), zero outside
+__device__ __forceinline__ u128 zf_load16(const u8* bs, i32 size, i32 byte)
+{
+    u128 v; v.lo = 0; v.hi = 0;
+    if (byte >= 0 && byte + 16 <= size) return ld128(bs + byte);
+    if (byte + 16 <= 0 || byte >= size) return v;
+    #pragma unroll 1
+    for (int i = 0; i < 16; i++) {
+        const i32 b = byte + i;
+        if (b >= 0 && b < size) { const u64 x = (u64)ld8(bs + b); if (i < 8) v.lo |= x << (8 * i); else v.hi |= x << (8 * (i - 8)); }
+    }
+    return v;
+}
+__device__ __forceinline__ void zf_ring_put(lds_p8 ring, i32 chunk, int sub, u128 v)
+{
+    const u32 slot = ((u32)chunk & 1u) * 256u;
+    lds_st128(ring + slot + 16u * (u32)sub, v);
+    if (slot == 0 && sub == 0) lds_st64(ring + ZF_RING, v.lo);
+}
+// n (<= 31) stream bits starting at bit `bit` (may be negative: zeros), out of the ring
+__device__ __forceinline__ u32 zf_bits(lds_cp8 ring, i32 bit, u32 n)
+{
+    const u32 idx = (u32)(bit >> 3) & (ZF_RING - 1u);
+    const u64 v = ((const ZPK_LDS pk64*)(ring + idx))->v;
+    return (u32)(v >> (bit & 7)) & ((1u << n) - 1u);
+}
+__device__ __forceinline__ u32 lds_ld32u(lds_cp8 p) { return ((const ZPK_LDS pk32*)p)->v; }
+
+// RFC 8878 4.1.1 out of a staged LDS buffer (row-uniform).  Returns bytes consumed or -1.
+__device__ __forceinline__ int zf_read_ncount(lds_cp8 buf, u32 size, u32 room, int max_sym, int max_al, ZPK_LDS i16* nc, int& nsym, int& al_out)
+{
+    u32 bit = 0;
+    #define ZF_RD(n) ({ const u32 w_ = lds_ld32u(buf + (bit >> 3)); const u32 v_ = (w_ >> (bit & 7)) & ((1u << (n)) - 1u); bit += (u32)(n); v_; })
+    const int al = 5 + (int)ZF_RD(4);
+    if (al > max_al) return -1;
+    int remaining = 1 << al;
+    int s = 0;
+    while (remaining > 0 && s <= max_sym) {
+        if ((bit >> 3) + 4u > room) return -1;                 // `room` readable (staged or zeroed) bytes follow buf
+        const int nb = highbit32((u32)remaining + 1) + 1;
+        u32 val = ZF_RD(nb);
+        const u32 lower_mask = (1u << (nb - 1)) - 1;
+        const u32 threshold = (1u << nb) - 1 - ((u32)remaining + 1);
+        if ((val & lower_mask) < threshold) { bit -= 1; val &= lower_mask; }
+        else if (val > lower_mask) val -= threshold;
+        const int proba = (int)val - 1;
+        remaining -= proba < 0 ? 1 : proba;
+        nc[s] = (i16)proba;
+        s++;
+        if (proba == 0) {
+            u32 rep = ZF_RD(2);
+            for (;;) {
+                for (u32 i = 0; i < rep; i++) {
+                    if (s > max_sym) return -1;
+                    nc[s] = 0;
+                    s++;
+                }
+                if (rep != 3) break;
+                if ((bit >> 3) + 4u > room) return -1;
+                rep = ZF_RD(2);
+            }
+        }
+    }
+    #undef ZF_RD
+    if (remaining != 0) return -1;
+    const u32 used = (bit + 7) >> 3;
+    if (used > size) return -1;
+    nsym = s; al_out = al;
+    return (int)used;
+}
+
+enum { ZF_NEED_ENTRY = 0, ZF_NEED_FRAME = 1, ZF_NEED_BLOCK = 2, ZF_DECODING = 3, ZF_DONE = 4 };
+
+// state[e] = 1: entry e's sequences are in the arena (region of its output slot, 8 bytes per sequence); 0: not.
+__global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
+                                                 const u32* __restrict__ list, u32* __restrict__ counters,
+                                                 u64* __restrict__ arena, u32* __restrict__ state, u64* __restrict__ zdbg)
+{
+    __shared__ ZfShared sh;
+    const int lane = lane_id();
+    const int row = lane >> 4, sub = lane & 15;
+    ZPK_LDS ZfRow* const R = (ZPK_LDS ZfRow*)&sh.row[row];
+    const lds_p8 ring = (lds_p8)R->ring;
+
+    // ---- predefined tables + symbol tables, once per workgroup ----
+    for (int i = lane; i < 36; i += WAVE) { sh.row[0].ncount[0][i] = Z_LL_DEF[i]; sh.symtab_ll[i] = Z_LL_BASE[i] | ((u32)Z_LL_BITS[i] << 24); }
+    for (int i = lane; i < 29; i += WAVE) sh.row[1].ncount[0][i] = Z_OF_DEF[i];
+    for (int i = lane; i < 53; i += WAVE) { sh.row[2].ncount[0][i] = Z_ML_DEF[i]; sh.symtab_ml[i] = Z_ML_BASE[i] | ((u32)Z_ML_BITS[i] << 24); }
+    __syncthreads();
+    if (lane < 3) {
+        ZPK_LDS FseCell* const t = lane == T_LL ? (ZPK_LDS FseCell*)sh.dll : (lane == T_OF ? (ZPK_LDS FseCell*)sh.dof : (ZPK_LDS FseCell*)sh.dml);
+        const ZPK_LDS u32* const st = lane == T_LL ? (const ZPK_LDS u32*)sh.symtab_ll : (const ZPK_LDS u32*)sh.symtab_ml;
+        fse_build_inplace(t, (ZPK_LDS i16*)sh.row[lane].ncount[0], lane == T_LL ? 36 : (lane == T_OF ? 29 : 53), lane == T_OF ? 5 : 6, lane,
+                          lane == T_OF ? (const ZPK_LDS u32*)nullptr : st);
+    }
+    __syncthreads();
+
+    // ---- per-row state (row-uniform unless noted) ----
+    int phase = ZF_NEED_ENTRY;
+    u32 e = 0;
+    const u8* ip = nullptr; const u8* iend = nullptr;
+    u64 a_base = 0; u32 seq_cap = 0, seq_n = 0;
+    u32 rep0 = 1, rep1 = 4, rep2 = 8;
+    bool tables_valid = false, last_block = false, cksum = false, bad = false;
+    int al_ll = 0, al_of = 0, al_ml = 0;
+    u32 remaining = 0;
+    const u8* bs = nullptr; i32 bs_size = 0, pos = 0, loaded_lo = 0;
+    u128 pf; pf.lo = 0; pf.hi = 0;                       // per lane: its 16 bytes of the chunk below the ring
+    FseCell cell = 0;                                    // per lane (chain lanes)
+    // roles inside a row (zstd_wg.h): lanes 0,1,2 cut the OF, ML, LL value bits, lanes 7,6,5 the state bits of the same chains
+    const int role = sub < 3 ? sub : 7 - sub;            // 0 OF, 1 ML, 2 LL for chain lanes
+    const bool chain = sub < 3 || (sub >= 5 && sub < 8);
+    const ZPK_LDS u32* const tab = role == 0 ? (const ZPK_LDS u32*)R->of : (role == 1 ? (const ZPK_LDS u32*)R->ml : (const ZPK_LDS u32*)R->ll);
+    const ZPK_LDS u32* const symt = role == 2 ? (const ZPK_LDS u32*)sh.symtab_ll : (const ZPK_LDS u32*)sh.symtab_ml;
+    const u32 nz = counters[ZF_COUNT_WORD];
+    // A row must never hold the GPU: an entry gets ZPK_WATCHDOG_SECONDS (like the fused decoder), and the header
+    // loop a fixed budget of steps per wave; either limit just hands the entry (or the rest of the list) to k_zstd.
+    u64 row_deadline = 0;
+    u32 tick = 0, setup_steps = 0;
+
+    for (;;) {
+        if (((++tick) & 1023u) == 0 && phase != ZF_DONE && phase != ZF_NEED_ENTRY && __builtin_amdgcn_s_memrealtime() > row_deadline) {
+            bad = true; ip = iend; phase = ZF_NEED_FRAME;
+            lane0_guard();
+            if (sub == 0) atomicAdd(&counters[ZF_WATCHDOG_WORD], 1u);
+            lane0_guard();
+        }
+        // =================== between blocks: headers, tables, stream start (divergent, rare) ===================
+        if (phase < ZF_DECODING) {
+            for (;;) {
+                if (++setup_steps > (1u << 24)) {                      // cannot happen: every step consumes input or finishes an entry
+                    lane0_guard();
+                    if (sub == 0) atomicAdd(&counters[ZF_WATCHDOG_WORD + 1], 1u);
+                    lane0_guard();
+                    phase = ZF_DONE; break;
+                }
+                if (phase == ZF_NEED_ENTRY) {
+                    lane0_guard();
+                    u32 v = 0;
+                    if (sub == 0) v = atomicAdd(&counters[ZF_HEAD], 1u);
+                    lane0_guard();
+                    v = (u32)__shfl((int)v, lane & ~15, 64);
+                    if (v >= nz) { phase = ZF_DONE; break; }
+                    e = list[v];
+                    const zpk_decode_desc d = desc[e];
+                    ip = src + d.src_offset; iend = ip + d.comp_size;
+                    const u64 lo8 = (d.dst_offset + 7) & ~7ull, hi8 = (d.dst_offset + d.dst_capacity) & ~7ull;
+                    a_base = lo8 >> 3;
+                    const u64 cap = hi8 > lo8 ? (hi8 - lo8) >> 3 : 0;
+                    seq_cap = cap > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)cap;
+                    seq_n = 0; bad = false;
+                    row_deadline = __builtin_amdgcn_s_memrealtime() + (u64)ZPK_WATCHDOG_SECONDS * 100000000ull;
+                    phase = ZF_NEED_FRAME;
+                }
+                if (phase == ZF_NEED_FRAME) {
+                    // frame header, as zstd_decode_wave
+                    if (ip >= iend) {                                  // every frame of the entry walked: flush and publish
+                        const u32 rem = seq_n & 15u;
+                        wave_mem_fence();
+                        if (!bad && rem && (u32)sub < rem) arena[a_base + (seq_n & ~15u) + (u32)sub] = R->seqbuf[sub];
+                        lane0_guard();
+                        if (sub == 0) { state[e] = bad ? 0u : 1u; if (!bad) atomicAdd(&counters[ZF_WATCHDOG_WORD + 2], 1u); }
+                        lane0_guard();
+                        phase = ZF_NEED_ENTRY;
+                        continue;
+                    }
+                    bool ok = iend - ip >= 4;
+                    u32 magic = ok ? ld32(ip) : 0u;
+                    if (ok && (magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+                        ok = iend - ip >= 8;
+                        const u64 sz = ok ? (u64)ld32(ip + 4) : 0;
+                        if (ok && (u64)(iend - ip) - 8 >= sz) { ip += 8 + sz; continue; }
+                        ok = false;
+                    }
+                    if (ok && magic != 0xFD2FB528u) ok = false;
+                    if (ok && iend - ip < 6) ok = false;
+                    if (ok) {
+                        ip += 4;
+                        const u32 fhd = ld8(ip++);
+                        const u32 fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+                        cksum = (fhd >> 2) & 1;
+                        if (fhd & 0x08) ok = false;
+                        if (ok && !single) {
+                            if (iend - ip < 1) ok = false;
+                            else { const u32 wdesc = ld8(ip++); if (10 + (wdesc >> 3) > 31) ok = false; }
+                        }
+                        const u32 dn = did_flag == 3 ? 4 : did_flag;
+                        if (ok && (u64)(iend - ip) < dn) ok = false;
+                        if (ok) { for (u32 i = 0; i < dn; i++) if (ld8(ip + i) != 0) ok = false; ip += dn; }
+                        const u32 fn = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+                        if (ok && (u64)(iend - ip) < fn) ok = false;
+                        if (ok) ip += fn;
+                    }
+                    if (!ok) { bad = true; ip = iend; continue; }       // leave the entry to the fused decoder
+                    rep0 = 1; rep1 = 4; rep2 = 8; tables_valid = false;
+                    phase = ZF_NEED_BLOCK;
+                }
+                // ---- ZF_NEED_BLOCK ----
+                if (iend - ip < 3) { bad = true; ip = iend; phase = ZF_NEED_FRAME; continue; }
+                const u32 bh = (u32)ld8(ip) | ((u32)ld8(ip + 1) << 8) | ((u32)ld8(ip + 2) << 16);
+                ip += 3;
+                last_block = bh & 1;
+                const u32 btype = (bh >> 1) & 3; const u64 bsize = bh >> 3;
+                bool ok = btype != 3;
+                u64 adv = btype == 1 ? 1 : bsize;
+                if (ok && adv > (u64)(iend - ip)) ok = false;
+                if (ok && btype == 2 && bsize >= ZSTD_BLOCK_MAX) ok = false;
+                if (!ok) { bad = true; ip = iend; phase = ZF_NEED_FRAME; continue; }
+                const u8* const blk = ip;
+                ip += adv;
+                bool to_decode = false;
+                if (btype == 2) {
+                    // literals section: only its size matters here (zstd_block)
+                    const u64 size = bsize;
+                    u64 used = 0;
+                    ok = size >= 3;
+                    if (ok) {
+                        const u32 b0 = ld8(blk);
+                        const u32 ltype = b0 & 3, fmt = (b0 >> 2) & 3;
+                        if (ltype < 2) {
+                            u64 hl, n;
+                            if ((fmt & 1) == 0) { hl = 1; n = b0 >> 3; }
+                            else if (fmt == 1) { hl = 2; n = (b0 >> 4) | ((u64)ld8(blk + 1) << 4); }
+                            else { hl = 3; n = (b0 >> 4) | ((u64)ld8(blk + 1) << 4) | ((u64)ld8(blk + 2) << 12); }
+                            used = ltype == 0 ? hl + n : hl + 1;
+                            if (n > ZSTD_BLOCK_MAX || used > size) ok = false;
+                        } else {
+                            if (size < 5) ok = false;
+                            else {
+                                const u64 v = ld32(blk);
+                                u64 hl, csize;
+                                if (fmt == 0 || fmt == 1) { hl = 3; csize = (v >> 14) & 0x3FF; }
+                                else if (fmt == 2) { hl = 4; csize = v >> 18; }
+                                else { hl = 5; csize = (v >> 22) | ((u64)ld8(blk + 4) << 10); }
+                                used = hl + csize;
+                                if (used > size) ok = false;
+                            }
+                        }
+                    }
+                    const u8* p = blk + used;
+                    u64 left = size - used;
+                    u64 nseq = 0;
+                    if (ok && left < 1) ok = false;
+                    if (ok) {
+                        nseq = ld8(p);
+                        if (nseq == 0) { if (left != 1) ok = false; p += 1; left -= 1; }
+                        else if (nseq < 128) { p += 1; left -= 1; }
+                        else if (nseq < 255) { if (left < 2) ok = false; else { nseq = ((nseq - 128) << 8) + ld8(p + 1); p += 2; left -= 2; } }
+                        else { if (left < 3) ok = false; else { nseq = (u64)ld8(p + 1) + ((u64)ld8(p + 2) << 8) + 0x7F00; p += 3; left -= 3; } }
+                    }
+                    if (ok && nseq > 0) {
+                        if (left < 1 || nseq > (u64)(seq_cap - seq_n)) ok = false;
+                        u32 modes = 0;
+                        if (ok) { modes = ld8(p); p += 1; left -= 1; }
+                        // stage up to 256 bytes of table descriptions in the (idle) ring
+                        const u32 avail = left < 256 ? (u32)left : 256u;
+                        if (ok) {
+                            wave_mem_fence();
+                            lds_st128(ring + 16u * (u32)sub, zf_load16(p, (i32)avail, 16 * sub));
+                            if (sub == 0) { u128 z; z.lo = 0; z.hi = 0; lds_st128(ring + 256, z); }
+                            wave_mem_fence();
+                        }
+                        u32 o = 0;                                       // bytes of descriptions consumed
+                        int pending = 0, ns[3] = {0, 0, 0};
+                        #pragma unroll 1
+                        for (int kind = 0; kind < 3 && ok; kind++) {      // T_LL, T_OF, T_ML: the order in the stream
+                            const int mode = (int)((modes >> (6 - 2 * kind)) & 3);
+                            ZPK_LDS FseCell* const t = kind == T_LL ? (ZPK_LDS FseCell*)R->ll : (kind == T_OF ? (ZPK_LDS FseCell*)R->of : (ZPK_LDS FseCell*)R->ml);
+                            const int max_sym = kind == T_LL ? 35 : (kind == T_OF ? 31 : 52);
+                            int al = 0;
+                            if (mode == 0) {
+                                const ZPK_LDS FseCell* const def = kind == T_LL ? (const ZPK_LDS FseCell*)sh.dll
+                                                                 : (kind == T_OF ? (const ZPK_LDS FseCell*)sh.dof : (const ZPK_LDS FseCell*)sh.dml);
+                                const int n = kind == T_OF ? 32 : 64;
+                                for (int i = sub; i < n; i += 16) t[i] = def[i];
+                                al = kind == T_OF ? 5 : 6;
+                            } else if (mode == 1) {
+                                if (o >= avail) ok = false;
+                                else {
+                                    const u32 s = lds_ld8((lds_cp8)ring + o);
+                                    if ((int)s > max_sym) ok = false;
+                                    else { t[0] = fse_rle_cell(kind, s); al = 0; o += 1; }
+                                }
+                            } else if (mode == 2) {
+                                int nsym = 0;
+                                const int used2 = o < avail ? zf_read_ncount((lds_cp8)ring + o, avail - o, 272u - o, max_sym, kind == T_OF ? 8 : 9,
+                                                                             (ZPK_LDS i16*)R->ncount[kind], nsym, al) : -1;
+                                if (used2 < 0) ok = false;
+                                else { o += (u32)used2; ns[kind] = nsym; pending |= 1 << kind; }
+                            } else {
+                                if (!tables_valid) ok = false;
+                                al = kind == T_LL ? al_ll : (kind == T_OF ? al_of : al_ml);
+                            }
+                            if (kind == T_LL) al_ll = al; else if (kind == T_OF) al_of = al; else al_ml = al;
+                        }
+                        if (ok) {
+                            wave_mem_fence();
+                            bool bok = true;
+                            const int kd = sub < 3 ? sub : 0;
+                            if (sub < 3 && ((pending >> kd) & 1)) {
+                                ZPK_LDS FseCell* const t = kd == T_LL ? (ZPK_LDS FseCell*)R->ll : (kd == T_OF ? (ZPK_LDS FseCell*)R->of : (ZPK_LDS FseCell*)R->ml);
+                                const ZPK_LDS u32* const st = kd == T_LL ? (const ZPK_LDS u32*)sh.symtab_ll : (const ZPK_LDS u32*)sh.symtab_ml;
+                                bok = fse_build_inplace(t, (ZPK_LDS i16*)R->ncount[kd], kd == T_LL ? ns[T_LL] : (kd == T_OF ? ns[T_OF] : ns[T_ML]),
+                                                        kd == T_LL ? al_ll : (kd == T_OF ? al_of : al_ml), kd,
+                                                        kd == T_OF ? (const ZPK_LDS u32*)nullptr : st);
+                            }
+                            wave_mem_fence();
+                            if (((__ballot(!bok) >> (16 * row)) & 0xFFFFull) != 0) ok = false;
+                        }
+                        if (ok) {
+                            tables_valid = true;
+                            // ---- backward bitstream [bs, bs + bs_size) ----
+                            bs = p + o; const u64 bsz = left - o;
+                            const u32 lastb = bsz ? (u32)ld8(bs + bsz - 1) : 0u;
+                            if (lastb == 0) ok = false;
+                            else {
+                                bs_size = (i32)bsz;
+                                pos = (i32)(bsz - 1) * 8 + highbit32(lastb);
+                                const i32 kt = (pos - 1) >> 11;
+                                const u128 c0 = zf_load16(bs, bs_size, 256 * kt + 16 * sub);
+                                const u128 c1 = zf_load16(bs, bs_size, 256 * (kt - 1) + 16 * sub);
+                                pf = zf_load16(bs, bs_size, 256 * (kt - 2) + 16 * sub);
+                                wave_mem_fence();
+                                zf_ring_put(ring, kt, sub, c0);
+                                zf_ring_put(ring, kt - 1, sub, c1);
+                                wave_mem_fence();
+                                loaded_lo = kt - 1;
+                                // initial states: LL, OF, ML
+                                pos -= al_ll; const u32 sll = zf_bits((lds_cp8)ring, pos, (u32)al_ll);
+                                pos -= al_of; const u32 sof = zf_bits((lds_cp8)ring, pos, (u32)al_of);
+                                pos -= al_ml; const u32 sml = zf_bits((lds_cp8)ring, pos, (u32)al_ml);
+                                cell = tab[role == 0 ? sof : (role == 1 ? sml : (chain ? sll : 0u))];
+                                remaining = (u32)nseq;
+                                to_decode = true;
+                            }
+                        }
+                    }
+                    if (!ok) { bad = true; ip = iend; phase = ZF_NEED_FRAME; continue; }
+                }
+                if (to_decode) { phase = ZF_DECODING; break; }
+                if (last_block) {
+                    if (cksum) { if (iend - ip < 4) { bad = true; ip = iend; } else ip += 4; }
+                    phase = ZF_NEED_FRAME;
+                } else phase = ZF_NEED_BLOCK;
+            }
+        }
+        if (__ballot(phase != ZF_DONE) == 0) break;
+
+        // =================== one sequence for every row that is inside a block ===================
+        if (phase == ZF_DECODING) {
+            if (((pos - 160) >> 11) < loaded_lo) {             // the next reads reach below the ring: bring in the prefetched chunk
+                wave_mem_fence();
+                zf_ring_put(ring, loaded_lo - 1, sub, pf);
+                wave_mem_fence();
+                loaded_lo -= 1;
+                pf = zf_load16(bs, bs_size, 256 * (loaded_lo - 1) + 16 * sub);
+            }
+            if (zdbg && sub == 0) zdbg[a_base + seq_n] = ((u64)(u32)pos << 32) | (u32)(loaded_lo & 0xFFFF) | ((u32)(tick & 0xFFFF) << 16);
+            const u32 sym = cell_sym(cell);
+            const u32 e_base = role == 0 ? (1u << (sym & 31u)) : (symt[sym] & 0xFFFFFFu);
+            u32 n = sub < 3 ? cell_add(cell) : cell_nb(cell);
+            n = chain ? n : 0u;
+            u32 s = n;                                           // inclusive prefix over the row (fields are consumed in lane order)
+            s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false);
+            s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false);
+            s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false);
+            u32 t = n;                                           // inclusive suffix: prefix + suffix - n = the sequence's total, in every lane
+            t += (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x101, 0xf, 0xf, false);      // row_shl:1
+            t += (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x102, 0xf, 0xf, false);
+            t += (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x104, 0xf, 0xf, false);
+            const u32 total = s + t - n;
+            const u32 bits = zf_bits((lds_cp8)ring, pos - (i32)s, n);
+            const u32 nst = cell_next(cell) + bits;              // lanes 5..7: next state (libzstd updates after the last sequence too)
+            const u32 nst_m = (u32)__builtin_amdgcn_update_dpp(0, (int)nst, 0x141, 0xf, 0xf, false);   // row_half_mirror
+            cell = tab[sub < 3 ? nst_m : (chain ? nst : 0u)];
+            const u32 val = e_base + bits;                       // lanes 0..2: offset value, match length, literal length
+            const u32 llv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE6, 0xf, 0xf, false);     // quad_perm [2,1,2,3]
+            const u32 mlv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE5, 0xf, 0xf, false);     // quad_perm [1,1,2,3]
+            u32 offset;
+            {   // repeat offsets (RFC 8878 3.1.1.5), meaningful in lane 0 of the row
+                const bool big = val > 3;
+                const u32 idx = val - 1 + (llv == 0 ? 1u : 0u);
+                u32 tt = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                if (tt == 0) tt = 1;
+                offset = big ? val - 3 : (idx == 0 ? rep0 : tt);
+                const bool shift = big || idx != 0;
+                const u32 n2 = (big || idx != 1) ? rep1 : rep2;
+                if (shift) { rep2 = n2; rep1 = rep0; rep0 = offset; }
+            }
+            lane0_guard();
+            if (sub == 0) {
+                if (offset == 0 || offset >= (1u << ZF_SEQ_OFF_BITS) || mlv >= (1u << ZF_SEQ_ML_BITS) || llv >= (1u << ZF_SEQ_LL_BITS)) bad = true;
+                R->seqbuf[seq_n & 15u] = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
+            }
+            bad = ((__ballot(bad) >> (16 * row)) & 0xFFFFull) != 0;
+            pos -= (i32)total;
+            // the three-step scans cover 8 lanes: `total` is right in lanes 0..7 only, and lanes 8..15 (which take part in
+            // the ring refills) take the position from them
+            pos = __builtin_amdgcn_update_dpp(pos, pos, 0x118, 0xf, 0xf, false);                       // row_shr:8
+            seq_n += 1;
+            if ((seq_n & 15u) == 0) {                            // 16 sequences = one 128-byte store
+                wave_mem_fence();
+                arena[a_base + (seq_n - 16u) + (u32)sub] = R->seqbuf[sub];
+                wave_mem_fence();
+            }
+            remaining -= 1;
+            if (remaining == 0 || bad) {
+                if (pos > 0) bad = true;                          // libzstd 1.4.9: the stream must not be under-consumed
+                if (bad) { ip = iend; phase = ZF_NEED_FRAME; }
+                else if (last_block) {
+                    if (cksum) { if (iend - ip < 4) { bad = true; ip = iend; } else ip += 4; }
+                    phase = ZF_NEED_FRAME;
+                } else phase = ZF_NEED_BLOCK;
+            }
+        }
+    }
+}
+
+}  // namespace zpk

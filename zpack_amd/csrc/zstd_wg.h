@@ -546,6 +546,8 @@ struct ZFrameState {
     u64 rep0, rep1, rep2;
     bool seq_tables_valid;
     int al_ll, al_of, al_ml;
+    const u64* pre;          // sequences of this entry already decoded by k_zstd_fse (zstd_fse4.h), or null
+    u64 pre_idx;             // sequences of the entry consumed so far
 };
 
 // sequences table for one of LL/OF/ML; returns bytes consumed or -1
@@ -594,7 +596,45 @@ struct ZSeqArgs {
     u64 lit_pos;                          // out: literals consumed
     u64 deadline; int timed_out;
     ZstdStats* zs;
+    const u64* pre;                       // this block's sequences, packed (zstd_fse4.h), when pre-decoded
 };
+
+// The same section when k_zstd_fse has already decoded it: 64 packed sequences per load, then execution.
+__device__ __noinline__ int zstd_sequences_pre(ZSeqArgs* a, int lane)
+{
+    const u64 nseq = uni64(a->nseq);
+    const u64* const pre = uni_ptr(a->pre);
+    const u8* const lit = uni_ptr(a->lit); const u64 lit_size = uni64(a->lit_size);
+    const bool lit_rle = a->lit_rle != 0; const u32 lit_rle_byte = a->lit_rle_byte;
+    u8* op = uni_ptr(a->op); u8* const oend = uni_ptr(a->oend); u8* const frame_lo = uni_ptr(a->frame_lo);
+    u64 lit_pos = 0;
+    u64 zt0 = SEQ_T(); (void)zt0;
+    for (u64 base = 0; base < nseq; base += WAVE) {
+        const int cnt = (int)(nseq - base < WAVE ? nseq - base : WAVE);
+        if (__builtin_amdgcn_s_memrealtime() > a->deadline) { a->timed_out = 1; return D_MALFORMED; }
+        u32 my_ll = 0, my_ml = 0, my_off = 1;
+        if (lane < cnt) {
+            const u64 v = *(const ZPK_GLOBAL u64*)(pre + base + (u64)lane);
+            my_off = (u32)v & ((1u << 29) - 1u); my_ml = (u32)(v >> 29) & ((1u << 18) - 1u); my_ll = (u32)(v >> 47);
+        }
+        u32 xl = wave_scan_add(lane < cnt ? my_ll : 0u);
+        const u64 lit_total = (u32)__builtin_amdgcn_readlane((int)xl, 63);
+        if (lit_total > lit_size - lit_pos) return D_MALFORMED;
+        if (__ballot(lane < cnt && my_off == 0) != 0) return D_MALFORMED;
+        SeqBatch q;
+        q.lit = lit + lit_pos + (xl - (lane < cnt ? my_ll : 0u));
+        q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = my_off;
+        SeqStats stt = {};
+        (void)stt;
+        const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt);
+        if (rc != D_OK) { a->op = op; return rc; }
+        lit_pos += lit_total;
+    }
+    ZST({ u64 t = SEQ_T(); a->zs->t_exec += t - zt0; zt0 = t; });
+    a->op = op; a->lit_pos = lit_pos;
+    return D_OK;
+}
+
 __device__ __noinline__ int zstd_sequences(ZPK_LDS ZstdShared* sh, ZSeqArgs* a, int lane)
 {
     ByteWindow win;
@@ -778,6 +818,13 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
     u64 lit_pos = 0;
     if (nseq > 0) {
         if (left < 1) return D_MALFORMED;
+        ZSeqArgs sa;
+        sa.pre = nullptr;
+        if (fs.pre) {
+            // k_zstd_fse has validated the tables and the bitstream of this block and decoded it
+            sa.pre = fs.pre + fs.pre_idx;
+            fs.pre_idx += nseq;
+        } else {
         const u32 modes = uld8(p);
         p += 1; left -= 1;
         int pending = 0, ns[3] = {0, 0, 0};
@@ -809,19 +856,19 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         __syncthreads();
         fs.seq_tables_valid = true;
         ZST({ u64 t = SEQ_T(); fs.zs->t_tab += t - zt0; zt0 = t; fs.zs->nseq += nseq; });
+        }
 
-        ZSeqArgs sa;
         sa.p = p; sa.left = left; sa.nseq = nseq;
         sa.al_ll = fs.al_ll; sa.al_of = fs.al_of; sa.al_ml = fs.al_ml;
         sa.rep0 = (u32)fs.rep0; sa.rep1 = (u32)fs.rep1; sa.rep2 = (u32)fs.rep2;
         sa.lit = lit; sa.lit_size = lit_size; sa.lit_rle = lit_rle ? 1 : 0; sa.lit_rle_byte = lit_rle_byte;
         sa.op = op; sa.oend = oend; sa.frame_lo = frame_lo; sa.lit_pos = 0;
         sa.deadline = fs.wd->deadline; sa.timed_out = 0; sa.zs = fs.zs;
-        const int src_rc = zstd_sequences((ZPK_LDS ZstdShared*)&sh, &sa, lane);
+        const int src_rc = sa.pre ? zstd_sequences_pre(&sa, lane) : zstd_sequences((ZPK_LDS ZstdShared*)&sh, &sa, lane);
         if (sa.timed_out) fs.wd->fired = true;
         op = sa.op;
         if (src_rc != D_OK) { produced = (u64)(op - dst); return src_rc; }
-        fs.rep0 = sa.rep0; fs.rep1 = sa.rep1; fs.rep2 = sa.rep2;
+        if (!sa.pre) { fs.rep0 = sa.rep0; fs.rep1 = sa.rep1; fs.rep2 = sa.rep2; }
         lit_pos = sa.lit_pos;
     }
     const u64 rest = lit_size - lit_pos;
@@ -857,8 +904,9 @@ __device__ inline void zstd_build_defaults(ZstdShared& sh, int lane)
 }
 
 __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u8* lit_buf, int lane,
-                                             ZstdStats* zs = nullptr)
+                                             ZstdStats* zs = nullptr, const u64* pre = nullptr)
 {
+    u64 pre_idx = 0;
     DecodeOut r; r.rc = D_OK; r.produced = 0;
     const u8* ip = src; const u8* iend = src + src_size;
     u8* op = dst; u8* oend = dst + dst_cap;
@@ -904,6 +952,7 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const
         ZFrameState fs;
         fs.wd = &wd; fs.zs = zs;
         fs.rep0 = 1; fs.rep1 = 4; fs.rep2 = 8; fs.seq_tables_valid = false; fs.al_ll = fs.al_of = fs.al_ml = 0;
+        fs.pre = pre; fs.pre_idx = pre_idx;
         lane0_guard();
         if (lane == 0) sh.huf_valid = 0;
         __syncthreads();
@@ -938,6 +987,7 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const
             if (last) break;
         }
         if (fail) break;
+        pre_idx = fs.pre_idx;
         if (fn != 0 && (u64)(op - frame_lo) != fcs) { r.rc = D_MALFORMED; break; }
         if (cksum) {
             if (iend - ip < 4) { r.rc = D_MALFORMED; break; }
