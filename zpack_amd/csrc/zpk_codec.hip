@@ -281,7 +281,6 @@ struct zpk_codec {
     u64* d_dbg = nullptr;        u64 dbg_cap = 0;
     u64* d_seq = nullptr;        u64 seq_cap = 0;      // encoder: sequence lists, one per workgroup
     u64* d_zarena = nullptr;     u64 zarena_cap = 0;   // decoder: pre-decoded Zstandard sequences, laid out like dst (zstd_fse4.h)
-    u64* d_zdbg = nullptr;       u64 zdbg_cap = 0;     // developer aid (ZPK_ZF_DEBUG=1): per-sequence stream positions
     u32* d_zstate = nullptr;     u64 zstate_cap = 0;   // decoder: per entry, 1 = its sequences are in the arena
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t kev[ZPK_K_COUNT][2] = {};
@@ -346,7 +345,7 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     (void)hipFree(c->d_counters); (void)hipFree(c->d_lists); (void)hipFree(c->d_lit);
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
-    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_zdbg);
+    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
@@ -403,15 +402,12 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     bool two_stage = !fused_only && dst_size >= 64;
     if (two_stage && (grow(c, (void**)&c->d_zarena, &c->zarena_cap, dst_size + 64) != ZPK_OK ||
                       grow(c, (void**)&c->d_zstate, &c->zstate_cap, n * sizeof(u32)) != ZPK_OK)) { two_stage = false; c->err[0] = 0; }
-    u64* zdbg = nullptr;
-    static const int zf_debug = getenv("ZPK_ZF_DEBUG") ? atoi(getenv("ZPK_ZF_DEBUG")) : 0;
-    if (zf_debug && two_stage && grow(c, (void**)&c->d_zdbg, &c->zdbg_cap, dst_size + 64) == ZPK_OK) zdbg = c->d_zdbg;
     ZPK_KEV(ZPK_K_ZSTD_FSE, 0);
     if (!(skip & 4) && two_stage) {
         HIPCHK(c, hipMemsetAsync(c->d_zstate, 0, n * sizeof(u32), st));          // entries k_zstd_fse never reaches stay unmarked
         const u64 zwaves = (n + ZF_ROWS - 1) / ZF_ROWS;
         hipLaunchKernelGGL(k_zstd_fse, dim3((u32)(zwaves < ZF_GRID_MAX ? zwaves : ZF_GRID_MAX)), dim3(64), 0, st, src, desc,
-                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_zarena, c->d_zstate, zdbg);
+                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_zarena, c->d_zstate);
     }
     ZPK_KEV(ZPK_K_ZSTD_FSE, 1);
     ZPK_TRACE_STEP("k_zstd_fse");
@@ -568,8 +564,8 @@ int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8])
 int zpk_codec_debug_fetch(zpk_codec* c, int what, uint64_t offset, void* host, uint64_t bytes)
 {
     if (!c || !host) return ZPK_E_INVALID;
-    const u8* base = what == 0 ? (const u8*)c->d_zarena : (what == 1 ? (const u8*)c->d_zstate : (const u8*)c->d_zdbg);
-    const u64 cap = what == 0 ? c->zarena_cap : (what == 1 ? c->zstate_cap : c->zdbg_cap);
+    const u8* base = what == 0 ? (const u8*)c->d_zarena : (const u8*)c->d_zstate;
+    const u64 cap = what == 0 ? c->zarena_cap : c->zstate_cap;
     if (!base || offset > cap || bytes > cap - offset) return ZPK_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());

@@ -43,13 +43,13 @@ struct alignas(16) ZfRow {
 struct alignas(16) ZfShared {
     ZfRow row[ZF_ROWS];
     FseCell dll[64], dml[64], dof[32];             // predefined distributions
-    u32 symtab_ll[36], symtab_ml[54];              // baseline | extra bits << 24
+    u32 base_ll[36], base_ml[54], base_of[32];     // value baselines of the LL / ML / OF codes
     u32 pad[2];
 };
 
 // Decode table from normalized counts, by ONE lane, in place: the spread symbols are parked in the table itself
 // and the next-state counters overwrite the counts.  Same construction as fse_build_lane (zstd_wg.h).
-__device__ __noinline__ bool fse_build_inplace(ZPK_LDS FseCell* tab, ZPK_LDS i16* nc, int nsym, int al, int kind, const ZPK_LDS u32* symtab)
+__device__ __noinline__ bool fse_build_inplace(ZPK_LDS FseCell* tab, ZPK_LDS i16* nc, int nsym, int al, int kind)
 {
     const int size = 1 << al;
     int high = size;
@@ -77,7 +77,7 @@ __device__ __noinline__ bool fse_build_inplace(ZPK_LDS FseCell* tab, ZPK_LDS i16
         const u32 n = (u32)(u16)nc[s];
         nc[s] = (i16)(n + 1);
         const u32 nb = (u32)al - (u32)highbit32(n);
-        const u32 add = symtab ? symtab[s] >> 24 : (kind == T_OF ? s : 0u);
+        const u32 add = kind == T_LL ? (u32)Z_LL_BITS[s < 36 ? s : 0] : (kind == T_ML ? (u32)Z_ML_BITS[s < 53 ? s : 0] : s);
         tab[i] = fse_cell((n << nb) - (u32)size, nb, add, s);
     }
     return true;
@@ -159,7 +159,7 @@ enum { ZF_NEED_ENTRY = 0, ZF_NEED_FRAME = 1, ZF_NEED_BLOCK = 2, ZF_DECODING = 3,
 // state[e] = 1: entry e's sequences are in the arena (region of its output slot, 8 bytes per sequence); 0: not.
 __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                  const u32* __restrict__ list, u32* __restrict__ counters,
-                                                 u64* __restrict__ arena, u32* __restrict__ state, u64* __restrict__ zdbg)
+                                                 u64* __restrict__ arena, u32* __restrict__ state)
 {
     __shared__ ZfShared sh;
     const int lane = lane_id();
@@ -168,15 +168,14 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
     const lds_p8 ring = (lds_p8)R->ring;
 
     // ---- predefined tables + symbol tables, once per workgroup ----
-    for (int i = lane; i < 36; i += WAVE) { sh.row[0].ncount[0][i] = Z_LL_DEF[i]; sh.symtab_ll[i] = Z_LL_BASE[i] | ((u32)Z_LL_BITS[i] << 24); }
+    for (int i = lane; i < 36; i += WAVE) { sh.row[0].ncount[0][i] = Z_LL_DEF[i]; sh.base_ll[i] = Z_LL_BASE[i]; }
     for (int i = lane; i < 29; i += WAVE) sh.row[1].ncount[0][i] = Z_OF_DEF[i];
-    for (int i = lane; i < 53; i += WAVE) { sh.row[2].ncount[0][i] = Z_ML_DEF[i]; sh.symtab_ml[i] = Z_ML_BASE[i] | ((u32)Z_ML_BITS[i] << 24); }
+    for (int i = lane; i < 32; i += WAVE) sh.base_of[i] = 1u << i;
+    for (int i = lane; i < 54; i += WAVE) { if (i < 53) sh.row[2].ncount[0][i] = Z_ML_DEF[i]; sh.base_ml[i] = i < 53 ? Z_ML_BASE[i] : 0u; }
     __syncthreads();
     if (lane < 3) {
         ZPK_LDS FseCell* const t = lane == T_LL ? (ZPK_LDS FseCell*)sh.dll : (lane == T_OF ? (ZPK_LDS FseCell*)sh.dof : (ZPK_LDS FseCell*)sh.dml);
-        const ZPK_LDS u32* const st = lane == T_LL ? (const ZPK_LDS u32*)sh.symtab_ll : (const ZPK_LDS u32*)sh.symtab_ml;
-        fse_build_inplace(t, (ZPK_LDS i16*)sh.row[lane].ncount[0], lane == T_LL ? 36 : (lane == T_OF ? 29 : 53), lane == T_OF ? 5 : 6, lane,
-                          lane == T_OF ? (const ZPK_LDS u32*)nullptr : st);
+        fse_build_inplace(t, (ZPK_LDS i16*)sh.row[lane].ncount[0], lane == T_LL ? 36 : (lane == T_OF ? 29 : 53), lane == T_OF ? 5 : 6, lane);
     }
     __syncthreads();
 
@@ -196,15 +195,19 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
     const int role = sub < 3 ? sub : 7 - sub;            // 0 OF, 1 ML, 2 LL for chain lanes
     const bool chain = sub < 3 || (sub >= 5 && sub < 8);
     const ZPK_LDS u32* const tab = role == 0 ? (const ZPK_LDS u32*)R->of : (role == 1 ? (const ZPK_LDS u32*)R->ml : (const ZPK_LDS u32*)R->ll);
-    const ZPK_LDS u32* const symt = role == 2 ? (const ZPK_LDS u32*)sh.symtab_ll : (const ZPK_LDS u32*)sh.symtab_ml;
+    const ZPK_LDS u32* const symt = role == 0 ? (const ZPK_LDS u32*)sh.base_of : (role == 2 ? (const ZPK_LDS u32*)sh.base_ll : (const ZPK_LDS u32*)sh.base_ml);
+    const u32 nsh = sub < 3 ? 14u : 10u;                 // where this lane's field width sits in a cell: add_bits (value lanes) / nb_bits (state lanes)
+    const u32 nmask = sub < 3 ? 31u : (chain ? 15u : 0u);
+    const u32 tmask = chain ? 1023u : 0u;                // idle lanes read cell 0
+    u32 badv = 0;
     const u32 nz = counters[ZF_COUNT_WORD];
     // A row must never hold the GPU: an entry gets ZPK_WATCHDOG_SECONDS (like the fused decoder), and the header
     // loop a fixed budget of steps per wave; either limit just hands the entry (or the rest of the list) to k_zstd.
     u64 row_deadline = 0;
-    u32 tick = 0, setup_steps = 0;
+    u32 setup_steps = 0;
 
     for (;;) {
-        if (((++tick) & 1023u) == 0 && phase != ZF_DONE && phase != ZF_NEED_ENTRY && __builtin_amdgcn_s_memrealtime() > row_deadline) {
+        if (phase != ZF_DONE && phase != ZF_NEED_ENTRY && __builtin_amdgcn_s_memrealtime() > row_deadline) {
             bad = true; ip = iend; phase = ZF_NEED_FRAME;
             lane0_guard();
             if (sub == 0) atomicAdd(&counters[ZF_WATCHDOG_WORD], 1u);
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                     a_base = lo8 >> 3;
                     const u64 cap = hi8 > lo8 ? (hi8 - lo8) >> 3 : 0;
                     seq_cap = cap > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)cap;
-                    seq_n = 0; bad = false;
+                    seq_n = 0; bad = false; badv = 0;
                     row_deadline = __builtin_amdgcn_s_memrealtime() + (u64)ZPK_WATCHDOG_SECONDS * 100000000ull;
                     phase = ZF_NEED_FRAME;
                 }
@@ -384,10 +387,8 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                             const int kd = sub < 3 ? sub : 0;
                             if (sub < 3 && ((pending >> kd) & 1)) {
                                 ZPK_LDS FseCell* const t = kd == T_LL ? (ZPK_LDS FseCell*)R->ll : (kd == T_OF ? (ZPK_LDS FseCell*)R->of : (ZPK_LDS FseCell*)R->ml);
-                                const ZPK_LDS u32* const st = kd == T_LL ? (const ZPK_LDS u32*)sh.symtab_ll : (const ZPK_LDS u32*)sh.symtab_ml;
                                 bok = fse_build_inplace(t, (ZPK_LDS i16*)R->ncount[kd], kd == T_LL ? ns[T_LL] : (kd == T_OF ? ns[T_OF] : ns[T_ML]),
-                                                        kd == T_LL ? al_ll : (kd == T_OF ? al_of : al_ml), kd,
-                                                        kd == T_OF ? (const ZPK_LDS u32*)nullptr : st);
+                                                        kd == T_LL ? al_ll : (kd == T_OF ? al_of : al_ml), kd);
                             }
                             wave_mem_fence();
                             if (((__ballot(!bok) >> (16 * row)) & 0xFFFFull) != 0) ok = false;
@@ -431,66 +432,62 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
         }
         if (__ballot(phase != ZF_DONE) == 0) break;
 
-        // =================== one sequence for every row that is inside a block ===================
+        // =================== rows inside a block: one sequence per trip, until a row's block ends ===================
+        // The loop runs under the exec mask of the decoding rows, its only exit test is wave-uniform, and everything a
+        // lane needs to know about its role is a VGPR constant (no per-role exec masks: they were SGPR spills).
         if (phase == ZF_DECODING) {
-            if (((pos - 160) >> 11) < loaded_lo) {             // the next reads reach below the ring: bring in the prefetched chunk
-                wave_mem_fence();
-                zf_ring_put(ring, loaded_lo - 1, sub, pf);
-                wave_mem_fence();
-                loaded_lo -= 1;
-                pf = zf_load16(bs, bs_size, 256 * (loaded_lo - 1) + 16 * sub);
-            }
-            if (zdbg && sub == 0) zdbg[a_base + seq_n] = ((u64)(u32)pos << 32) | (u32)(loaded_lo & 0xFFFF) | ((u32)(tick & 0xFFFF) << 16);
-            const u32 sym = cell_sym(cell);
-            const u32 e_base = role == 0 ? (1u << (sym & 31u)) : (symt[sym] & 0xFFFFFFu);
-            u32 n = sub < 3 ? cell_add(cell) : cell_nb(cell);
-            n = chain ? n : 0u;
-            u32 s = n;                                           // inclusive prefix over the row (fields are consumed in lane order)
-            s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false);
-            s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false);
-            s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false);
-            u32 t = n;                                           // inclusive suffix: prefix + suffix - n = the sequence's total, in every lane
-            t += (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x101, 0xf, 0xf, false);      // row_shl:1
-            t += (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x102, 0xf, 0xf, false);
-            t += (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x104, 0xf, 0xf, false);
-            const u32 total = s + t - n;
-            const u32 bits = zf_bits((lds_cp8)ring, pos - (i32)s, n);
-            const u32 nst = cell_next(cell) + bits;              // lanes 5..7: next state (libzstd updates after the last sequence too)
-            const u32 nst_m = (u32)__builtin_amdgcn_update_dpp(0, (int)nst, 0x141, 0xf, 0xf, false);   // row_half_mirror
-            cell = tab[sub < 3 ? nst_m : (chain ? nst : 0u)];
-            const u32 val = e_base + bits;                       // lanes 0..2: offset value, match length, literal length
-            const u32 llv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE6, 0xf, 0xf, false);     // quad_perm [2,1,2,3]
-            const u32 mlv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE5, 0xf, 0xf, false);     // quad_perm [1,1,2,3]
-            u32 offset;
-            {   // repeat offsets (RFC 8878 3.1.1.5), meaningful in lane 0 of the row
-                const bool big = val > 3;
-                const u32 idx = val - 1 + (llv == 0 ? 1u : 0u);
-                u32 tt = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
-                if (tt == 0) tt = 1;
-                offset = big ? val - 3 : (idx == 0 ? rep0 : tt);
-                const bool shift = big || idx != 0;
-                const u32 n2 = (big || idx != 1) ? rep1 : rep2;
-                if (shift) { rep2 = n2; rep1 = rep0; rep0 = offset; }
-            }
-            lane0_guard();
-            if (sub == 0) {
-                if (offset == 0 || offset >= (1u << ZF_SEQ_OFF_BITS) || mlv >= (1u << ZF_SEQ_ML_BITS) || llv >= (1u << ZF_SEQ_LL_BITS)) bad = true;
-                R->seqbuf[seq_n & 15u] = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
-            }
-            bad = ((__ballot(bad) >> (16 * row)) & 0xFFFFull) != 0;
-            pos -= (i32)total;
-            // the three-step scans cover 8 lanes: `total` is right in lanes 0..7 only, and lanes 8..15 (which take part in
-            // the ring refills) take the position from them
-            pos = __builtin_amdgcn_update_dpp(pos, pos, 0x118, 0xf, 0xf, false);                       // row_shr:8
-            seq_n += 1;
-            if ((seq_n & 15u) == 0) {                            // 16 sequences = one 128-byte store
-                wave_mem_fence();
-                arena[a_base + (seq_n - 16u) + (u32)sub] = R->seqbuf[sub];
-                wave_mem_fence();
-            }
-            remaining -= 1;
-            if (remaining == 0 || bad) {
-                if (pos > 0) bad = true;                          // libzstd 1.4.9: the stream must not be under-consumed
+            do {
+                const u32 n = (cell >> nsh) & nmask;                 // this lane's field width: value bits (lanes 0..2) / state bits (5..7)
+                u32 s = n;                                           // inclusive prefix over the row: fields are consumed in lane order
+                s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false);
+                s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false);
+                s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false);
+                const u32 total = (u32)__builtin_amdgcn_ds_swizzle((int)s, 0xF0);       // lane 7 of the row -> all 16 lanes
+                const u32 base = symt[cell_sym(cell)];
+                const i32 b = pos - (i32)s;
+                const u64 w = ((const ZPK_LDS pk64*)(ring + ((u32)(b >> 3) & (ZF_RING - 1u))))->v;
+                const u32 bits = (u32)(w >> (b & 7)) & ((1u << n) - 1u);
+                const u32 nst = cell_next(cell) + bits;              // lanes 5..7: next state (libzstd updates after the last sequence too)
+                // lanes 0..3 take the mirrored lane's state (bank 0 of the row), lanes 4..7 keep their own
+                const u32 idx = (u32)__builtin_amdgcn_update_dpp((int)nst, (int)nst, 0x141, 0xf, 0x5, false);
+                cell = tab[idx & tmask];
+                const u32 val = base + bits;                         // lanes 0..2: offset value, match length, literal length
+                const u32 llv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE6, 0xf, 0xf, false);     // quad_perm [2,1,2,3]
+                const u32 mlv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE5, 0xf, 0xf, false);     // quad_perm [1,1,2,3]
+                u32 offset;
+                {   // repeat offsets (RFC 8878 3.1.1.5), meaningful in lane 0 of the row
+                    const bool big = val > 3;
+                    const u32 ridx = val - 1 + (llv == 0 ? 1u : 0u);
+                    u32 tt = ridx == 3 ? rep0 - 1 : (ridx == 1 ? rep1 : rep2);
+                    if (tt == 0) tt = 1;
+                    offset = big ? val - 3 : (ridx == 0 ? rep0 : tt);
+                    const bool shift = big || ridx != 0;
+                    const u32 n2 = (big || ridx != 1) ? rep1 : rep2;
+                    if (shift) { rep2 = n2; rep1 = rep0; rep0 = offset; }
+                }
+                // what does not fit the packing (or is corrupt) sends the entry to the fused decoder at the end of the block
+                badv |= (offset - 1u >= (1u << ZF_SEQ_OFF_BITS) - 1u ? 1u : 0u) | (mlv >> ZF_SEQ_ML_BITS) | (llv >> ZF_SEQ_LL_BITS);
+                if (sub == 0) R->seqbuf[seq_n & 15u] = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
+                pos -= (i32)total;
+                seq_n += 1;
+                remaining -= 1;
+                if ((seq_n & 15u) == 0) {                            // 16 sequences = one 128-byte store
+                    wave_mem_fence();
+                    arena[a_base + (seq_n - 16u) + (u32)sub] = R->seqbuf[sub];
+                    wave_mem_fence();
+                }
+                if (((pos - 160) >> 11) < loaded_lo) {             // the next reads reach below the ring: bring in the prefetched chunk
+                    wave_mem_fence();
+                    zf_ring_put(ring, loaded_lo - 1, sub, pf);
+                    wave_mem_fence();
+                    loaded_lo -= 1;
+                    pf = zf_load16(bs, bs_size, 256 * (loaded_lo - 1) + 16 * sub);
+                }
+            } while (__ballot(remaining == 0) == 0);
+            if (remaining == 0) {                                    // this row's block is done
+                // lane 0 of the row saw every sequence; libzstd 1.4.9: the stream must not be under-consumed
+                const u64 bm = __ballot(sub == 0 && badv != 0);
+                if (((bm >> (16 * row)) & 1ull) != 0 || pos > 0) bad = true;
                 if (bad) { ip = iend; phase = ZF_NEED_FRAME; }
                 else if (last_block) {
                     if (cksum) { if (iend - ip < 4) { bad = true; ip = iend; } else ip += 4; }
