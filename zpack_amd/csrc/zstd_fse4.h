@@ -29,33 +29,42 @@ namespace zpk {
 #define ZF_SEQ_OFF_BITS 29                         // packed sequence: offset | match length << 29 | literal length << 47
 #define ZF_SEQ_ML_BITS 18
 #define ZF_SEQ_LL_BITS 17
-#define ZF_GRID_MAX (256u * 6u)                    // 6 workgroups per CU (LDS: 25.6 KiB each)
+#define ZF_GRID_MAX (256u * 8u)                    // 8 workgroups per CU (LDS: 20 KiB each)
 #define ZF_HEAD 8                                  // counters[] word used as this kernel's dequeue head
 #define ZF_WATCHDOG_WORD 11                        // counters[11]: entries given up by the row watchdog, [12]: header-loop budget hits
 #define ZF_COUNT_WORD 1                            // counters[] word holding the length of the Zstandard work list (L_ZSTD)
 
-struct alignas(16) ZfRow {
-    FseCell ll[512], ml[512], of[256];
-    u8  ring[ZF_RING + 16];                        // + mirror of the first 8 bytes (reads are 8 bytes wide at any byte offset)
-    i16 ncount[3][64];                             // normalized counts, then (in place) the per-symbol next-state counters
+// A decode-table cell takes 3 bytes here, split over two arrays so that LDS — which is what bounds the number of
+// streams in flight — holds 3.75 KiB of tables per stream instead of 5:
+//   s[i] (u16) = next_base (9 bits) | nb_bits << 9 (4) | (add_bits & 7) << 13        v[i] (u8) = add_bits >> 3 | symbol << 2
+// and a lane reassembles cell = s | v << 16: next_base = cell & 511, nb_bits = cell >> 9 & 15, add_bits = cell >> 13 & 31
+// (contiguous across the two halves), symbol = cell >> 18.
+struct ZfTab { u16 s_ll[512], s_ml[512], s_of[256]; u8 v_ll[512], v_ml[512], v_of[256]; };
+struct alignas(8) ZfRow {
+    ZfTab t;
     u64 seqbuf[16];                                // 16 packed sequences: the row flushes them as one 128-byte store
+    u8  ring[ZF_RING + 8];                         // + mirror of the first 8 bytes (reads are 8 bytes wide at any byte offset)
+    i16 ncount[3][64];                             // normalized counts, then (in place) the per-symbol next-state counters
 };
 struct alignas(16) ZfShared {
     ZfRow row[ZF_ROWS];
-    FseCell dll[64], dml[64], dof[32];             // predefined distributions
-    u32 base_ll[36], base_ml[54], base_of[32];     // value baselines of the LL / ML / OF codes
-    u32 pad[2];
+    u16 ds_ll[64], ds_ml[64], ds_of[32];           // predefined distributions, same split
+    u8  dv_ll[64], dv_ml[64], dv_of[32];
+    u32 base_ll[36], base_ml[53], base_of[32];     // value baselines of the LL / ML / OF codes
 };
+__device__ __forceinline__ u32 zf_cell(u32 next_base, u32 nb, u32 add, u32 sym) { return next_base | (nb << 9) | (add << 13) | (sym << 18); }
+__device__ __forceinline__ u32 zf_next(u32 c) { return c & 511u; }
+__device__ __forceinline__ u32 zf_sym(u32 c)  { return (c >> 18) & 63u; }
 
 // Decode table from normalized counts, by ONE lane, in place: the spread symbols are parked in the table itself
 // and the next-state counters overwrite the counts.  Same construction as fse_build_lane (zstd_wg.h).
-__device__ __noinline__ bool fse_build_inplace(ZPK_LDS FseCell* tab, ZPK_LDS i16* nc, int nsym, int al, int kind)
+__device__ __noinline__ bool fse_build_inplace(ZPK_LDS u16* ts, ZPK_LDS u8* tv, ZPK_LDS i16* nc, int nsym, int al, int kind)
 {
     const int size = 1 << al;
     int high = size;
     #pragma unroll 1
     for (int s = 0; s < nsym; s++)
-        if (nc[s] == -1) tab[--high] = (u32)s;
+        if (nc[s] == -1) tv[--high] = (u8)s;
     const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     int pos = 0;
     #pragma unroll 1
@@ -64,7 +73,7 @@ __device__ __noinline__ bool fse_build_inplace(ZPK_LDS FseCell* tab, ZPK_LDS i16
         if (f <= 0) continue;
         #pragma unroll 1
         for (int i = 0; i < f; i++) {
-            if (pos < high) tab[pos] = (u32)s;                  // positions >= high belong to the -1 symbols: skipped below
+            if (pos < high) tv[pos] = (u8)s;                    // positions >= high belong to the -1 symbols: skipped below
             do { pos = (pos + step) & mask; } while (pos >= high);
         }
     }
@@ -73,12 +82,13 @@ __device__ __noinline__ bool fse_build_inplace(ZPK_LDS FseCell* tab, ZPK_LDS i16
     for (int s = 0; s < nsym; s++) { const int f = nc[s]; nc[s] = (i16)(f == -1 ? 1 : (f > 0 ? f : 0)); }
     #pragma unroll 1
     for (int i = 0; i < size; i++) {
-        const u32 s = tab[i];
+        const u32 s = tv[i];
         const u32 n = (u32)(u16)nc[s];
         nc[s] = (i16)(n + 1);
         const u32 nb = (u32)al - (u32)highbit32(n);
         const u32 add = kind == T_LL ? (u32)Z_LL_BITS[s < 36 ? s : 0] : (kind == T_ML ? (u32)Z_ML_BITS[s < 53 ? s : 0] : s);
-        tab[i] = fse_cell((n << nb) - (u32)size, nb, add, s);
+        const u32 c = zf_cell((n << nb) - (u32)size, nb, add, s);
+        ts[i] = (u16)c; tv[i] = (u8)(c >> 16);
     }
     return true;
 }
@@ -171,11 +181,12 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
     for (int i = lane; i < 36; i += WAVE) { sh.row[0].ncount[0][i] = Z_LL_DEF[i]; sh.base_ll[i] = Z_LL_BASE[i]; }
     for (int i = lane; i < 29; i += WAVE) sh.row[1].ncount[0][i] = Z_OF_DEF[i];
     for (int i = lane; i < 32; i += WAVE) sh.base_of[i] = 1u << i;
-    for (int i = lane; i < 54; i += WAVE) { if (i < 53) sh.row[2].ncount[0][i] = Z_ML_DEF[i]; sh.base_ml[i] = i < 53 ? Z_ML_BASE[i] : 0u; }
+    for (int i = lane; i < 53; i += WAVE) { sh.row[2].ncount[0][i] = Z_ML_DEF[i]; sh.base_ml[i] = Z_ML_BASE[i]; }
     __syncthreads();
     if (lane < 3) {
-        ZPK_LDS FseCell* const t = lane == T_LL ? (ZPK_LDS FseCell*)sh.dll : (lane == T_OF ? (ZPK_LDS FseCell*)sh.dof : (ZPK_LDS FseCell*)sh.dml);
-        fse_build_inplace(t, (ZPK_LDS i16*)sh.row[lane].ncount[0], lane == T_LL ? 36 : (lane == T_OF ? 29 : 53), lane == T_OF ? 5 : 6, lane);
+        ZPK_LDS u16* const ts = lane == T_LL ? (ZPK_LDS u16*)sh.ds_ll : (lane == T_OF ? (ZPK_LDS u16*)sh.ds_of : (ZPK_LDS u16*)sh.ds_ml);
+        ZPK_LDS u8* const tv = lane == T_LL ? (ZPK_LDS u8*)sh.dv_ll : (lane == T_OF ? (ZPK_LDS u8*)sh.dv_of : (ZPK_LDS u8*)sh.dv_ml);
+        fse_build_inplace(ts, tv, (ZPK_LDS i16*)sh.row[lane].ncount[0], lane == T_LL ? 36 : (lane == T_OF ? 29 : 53), lane == T_OF ? 5 : 6, lane);
     }
     __syncthreads();
 
@@ -190,15 +201,16 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
     u32 remaining = 0;
     const u8* bs = nullptr; i32 bs_size = 0, pos = 0, loaded_lo = 0;
     u128 pf; pf.lo = 0; pf.hi = 0;                       // per lane: its 16 bytes of the chunk below the ring
-    FseCell cell = 0;                                    // per lane (chain lanes)
+    u32 cell = 0;                                        // per lane (chain lanes): s | v << 16
     // roles inside a row (zstd_wg.h): lanes 0,1,2 cut the OF, ML, LL value bits, lanes 7,6,5 the state bits of the same chains
     const int role = sub < 3 ? sub : 7 - sub;            // 0 OF, 1 ML, 2 LL for chain lanes
     const bool chain = sub < 3 || (sub >= 5 && sub < 8);
-    const ZPK_LDS u32* const tab = role == 0 ? (const ZPK_LDS u32*)R->of : (role == 1 ? (const ZPK_LDS u32*)R->ml : (const ZPK_LDS u32*)R->ll);
+    const ZPK_LDS u16* const tabs = role == 0 ? (const ZPK_LDS u16*)R->t.s_of : (role == 1 ? (const ZPK_LDS u16*)R->t.s_ml : (const ZPK_LDS u16*)R->t.s_ll);
+    const ZPK_LDS u8* const tabv = role == 0 ? (const ZPK_LDS u8*)R->t.v_of : (role == 1 ? (const ZPK_LDS u8*)R->t.v_ml : (const ZPK_LDS u8*)R->t.v_ll);
     const ZPK_LDS u32* const symt = role == 0 ? (const ZPK_LDS u32*)sh.base_of : (role == 2 ? (const ZPK_LDS u32*)sh.base_ll : (const ZPK_LDS u32*)sh.base_ml);
-    const u32 nsh = sub < 3 ? 14u : 10u;                 // where this lane's field width sits in a cell: add_bits (value lanes) / nb_bits (state lanes)
+    const u32 nsh = sub < 3 ? 13u : 9u;                  // where this lane's field width sits in a cell: add_bits (value lanes) / nb_bits (state lanes)
     const u32 nmask = sub < 3 ? 31u : (chain ? 15u : 0u);
-    const u32 tmask = chain ? 1023u : 0u;                // idle lanes read cell 0
+    const u32 tmask = chain ? 511u : 0u;                 // idle lanes read cell 0
     u32 badv = 0;
     const u32 nz = counters[ZF_COUNT_WORD];
     // A row must never hold the GPU: an entry gets ZPK_WATCHDOG_SECONDS (like the fused decoder), and the header
@@ -353,21 +365,26 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                         #pragma unroll 1
                         for (int kind = 0; kind < 3 && ok; kind++) {      // T_LL, T_OF, T_ML: the order in the stream
                             const int mode = (int)((modes >> (6 - 2 * kind)) & 3);
-                            ZPK_LDS FseCell* const t = kind == T_LL ? (ZPK_LDS FseCell*)R->ll : (kind == T_OF ? (ZPK_LDS FseCell*)R->of : (ZPK_LDS FseCell*)R->ml);
+                            ZPK_LDS u16* const ts = kind == T_LL ? (ZPK_LDS u16*)R->t.s_ll : (kind == T_OF ? (ZPK_LDS u16*)R->t.s_of : (ZPK_LDS u16*)R->t.s_ml);
+                            ZPK_LDS u8* const tv = kind == T_LL ? (ZPK_LDS u8*)R->t.v_ll : (kind == T_OF ? (ZPK_LDS u8*)R->t.v_of : (ZPK_LDS u8*)R->t.v_ml);
                             const int max_sym = kind == T_LL ? 35 : (kind == T_OF ? 31 : 52);
                             int al = 0;
                             if (mode == 0) {
-                                const ZPK_LDS FseCell* const def = kind == T_LL ? (const ZPK_LDS FseCell*)sh.dll
-                                                                 : (kind == T_OF ? (const ZPK_LDS FseCell*)sh.dof : (const ZPK_LDS FseCell*)sh.dml);
+                                const ZPK_LDS u16* const dfs = kind == T_LL ? (const ZPK_LDS u16*)sh.ds_ll : (kind == T_OF ? (const ZPK_LDS u16*)sh.ds_of : (const ZPK_LDS u16*)sh.ds_ml);
+                                const ZPK_LDS u8* const dfv = kind == T_LL ? (const ZPK_LDS u8*)sh.dv_ll : (kind == T_OF ? (const ZPK_LDS u8*)sh.dv_of : (const ZPK_LDS u8*)sh.dv_ml);
                                 const int n = kind == T_OF ? 32 : 64;
-                                for (int i = sub; i < n; i += 16) t[i] = def[i];
+                                for (int i = sub; i < n; i += 16) { ts[i] = dfs[i]; tv[i] = dfv[i]; }
                                 al = kind == T_OF ? 5 : 6;
                             } else if (mode == 1) {
                                 if (o >= avail) ok = false;
                                 else {
                                     const u32 s = lds_ld8((lds_cp8)ring + o);
                                     if ((int)s > max_sym) ok = false;
-                                    else { t[0] = fse_rle_cell(kind, s); al = 0; o += 1; }
+                                    else {
+                                        const u32 add = kind == T_LL ? (u32)Z_LL_BITS[s] : (kind == T_ML ? (u32)Z_ML_BITS[s] : s);
+                                        const u32 c = zf_cell(0, 0, add, s);
+                                        ts[0] = (u16)c; tv[0] = (u8)(c >> 16); al = 0; o += 1;
+                                    }
                                 }
                             } else if (mode == 2) {
                                 int nsym = 0;
@@ -386,8 +403,9 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                             bool bok = true;
                             const int kd = sub < 3 ? sub : 0;
                             if (sub < 3 && ((pending >> kd) & 1)) {
-                                ZPK_LDS FseCell* const t = kd == T_LL ? (ZPK_LDS FseCell*)R->ll : (kd == T_OF ? (ZPK_LDS FseCell*)R->of : (ZPK_LDS FseCell*)R->ml);
-                                bok = fse_build_inplace(t, (ZPK_LDS i16*)R->ncount[kd], kd == T_LL ? ns[T_LL] : (kd == T_OF ? ns[T_OF] : ns[T_ML]),
+                                ZPK_LDS u16* const ts = kd == T_LL ? (ZPK_LDS u16*)R->t.s_ll : (kd == T_OF ? (ZPK_LDS u16*)R->t.s_of : (ZPK_LDS u16*)R->t.s_ml);
+                                ZPK_LDS u8* const tv = kd == T_LL ? (ZPK_LDS u8*)R->t.v_ll : (kd == T_OF ? (ZPK_LDS u8*)R->t.v_of : (ZPK_LDS u8*)R->t.v_ml);
+                                bok = fse_build_inplace(ts, tv, (ZPK_LDS i16*)R->ncount[kd], kd == T_LL ? ns[T_LL] : (kd == T_OF ? ns[T_OF] : ns[T_ML]),
                                                         kd == T_LL ? al_ll : (kd == T_OF ? al_of : al_ml), kd);
                             }
                             wave_mem_fence();
@@ -415,7 +433,8 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                                 pos -= al_ll; const u32 sll = zf_bits((lds_cp8)ring, pos, (u32)al_ll);
                                 pos -= al_of; const u32 sof = zf_bits((lds_cp8)ring, pos, (u32)al_of);
                                 pos -= al_ml; const u32 sml = zf_bits((lds_cp8)ring, pos, (u32)al_ml);
-                                cell = tab[role == 0 ? sof : (role == 1 ? sml : (chain ? sll : 0u))];
+                                const u32 st0 = role == 0 ? sof : (role == 1 ? sml : (chain ? sll : 0u));
+                                cell = (u32)tabs[st0] | ((u32)tabv[st0] << 16);
                                 remaining = (u32)nseq;
                                 to_decode = true;
                             }
@@ -443,14 +462,15 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                 s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false);
                 s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false);
                 const u32 total = (u32)__builtin_amdgcn_ds_swizzle((int)s, 0xF0);       // lane 7 of the row -> all 16 lanes
-                const u32 base = symt[cell_sym(cell)];
+                const u32 base = symt[zf_sym(cell)];
                 const i32 b = pos - (i32)s;
                 const u64 w = ((const ZPK_LDS pk64*)(ring + ((u32)(b >> 3) & (ZF_RING - 1u))))->v;
                 const u32 bits = (u32)(w >> (b & 7)) & ((1u << n) - 1u);
-                const u32 nst = cell_next(cell) + bits;              // lanes 5..7: next state (libzstd updates after the last sequence too)
+                const u32 nst = zf_next(cell) + bits;                // lanes 5..7: next state (libzstd updates after the last sequence too)
                 // lanes 0..3 take the mirrored lane's state (bank 0 of the row), lanes 4..7 keep their own
                 const u32 idx = (u32)__builtin_amdgcn_update_dpp((int)nst, (int)nst, 0x141, 0xf, 0x5, false);
-                cell = tab[idx & tmask];
+                const u32 ci = idx & tmask;
+                cell = (u32)tabs[ci] | ((u32)tabv[ci] << 16);
                 const u32 val = base + bits;                         // lanes 0..2: offset value, match length, literal length
                 const u32 llv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE6, 0xf, 0xf, false);     // quad_perm [2,1,2,3]
                 const u32 mlv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE5, 0xf, 0xf, false);     // quad_perm [1,1,2,3]
