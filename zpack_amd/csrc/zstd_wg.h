@@ -25,6 +25,7 @@ namespace zpk {
 #define ZSTD_WG_THREADS 64
 #define ZSTD_BLOCK_MAX (128u << 10)
 #define ZSTD_LIT_SCRATCH ((128u << 10) + 64)
+#define ZSEQ_LWIN 1024u               // literal window of the pre-decoded executor (LDS)
 #define ZSTD_GRID_MAX 3072            // 12 workgroups per CU (LDS-limited: 13 KiB each)
 
 // One FSE decode-table cell, packed into 32 bits (LDS is what limits how many entries a CU decodes at once):
@@ -600,8 +601,15 @@ struct ZSeqArgs {
 };
 
 // The same section when k_zstd_fse has already decoded it: 64 packed sequences per load, then execution.
-__device__ __noinline__ int zstd_sequences_pre(ZSeqArgs* a, int lane)
+__device__ __noinline__ int zstd_sequences_pre(ZPK_LDS ZstdShared* sh, ZSeqArgs* a, int lane)
 {
+    // the FSE decode tables are idle in this mode: their 5 KiB serve as the executor's batch assembly buffer (seq_exec.h)
+    // and as a 1 KiB window over the literal stream, refilled with one coalesced load when a batch leaves it, so that
+    // literal runs are read with ds_read_b128 instead of up to four exact-tail vector loads per lane
+    const lds_p8 asm_buf = (lds_p8)sh->ll;
+    const u32 asm_cap = 4096u - 64u;
+    const lds_p8 lwin = asm_buf + 4096u - 32u;            // ZSEQ_LWIN bytes + 16 of read slack, inside the 5 KiB
+    u64 win_lo = ~0ull;
     const u64 nseq = uni64(a->nseq);
     const u64* const pre = uni_ptr(a->pre);
     const u8* const lit = uni_ptr(a->lit); const u64 lit_size = uni64(a->lit_size);
@@ -609,24 +617,39 @@ __device__ __noinline__ int zstd_sequences_pre(ZSeqArgs* a, int lane)
     u8* op = uni_ptr(a->op); u8* const oend = uni_ptr(a->oend); u8* const frame_lo = uni_ptr(a->frame_lo);
     u64 lit_pos = 0;
     u64 zt0 = SEQ_T(); (void)zt0;
+    u64 nxt = 0;                                          // the next batch's packed sequences, loaded one batch ahead
+    if ((u64)lane < nseq) nxt = *(const ZPK_GLOBAL u64*)(pre + (u64)lane);
     for (u64 base = 0; base < nseq; base += WAVE) {
         const int cnt = (int)(nseq - base < WAVE ? nseq - base : WAVE);
         if (__builtin_amdgcn_s_memrealtime() > a->deadline) { a->timed_out = 1; return D_MALFORMED; }
         u32 my_ll = 0, my_ml = 0, my_off = 1;
-        if (lane < cnt) {
-            const u64 v = *(const ZPK_GLOBAL u64*)(pre + base + (u64)lane);
-            my_off = (u32)v & ((1u << 29) - 1u); my_ml = (u32)(v >> 29) & ((1u << 18) - 1u); my_ll = (u32)(v >> 47);
-        }
+        const u64 v = nxt;
+        if (base + WAVE + (u64)lane < nseq) nxt = *(const ZPK_GLOBAL u64*)(pre + base + WAVE + (u64)lane);
+        if (lane < cnt) { my_off = (u32)v & ((1u << 29) - 1u); my_ml = (u32)(v >> 29) & ((1u << 18) - 1u); my_ll = (u32)(v >> 47); }
         u32 xl = wave_scan_add(lane < cnt ? my_ll : 0u);
         const u64 lit_total = (u32)__builtin_amdgcn_readlane((int)xl, 63);
         if (lit_total > lit_size - lit_pos) return D_MALFORMED;
         if (__ballot(lane < cnt && my_off == 0) != 0) return D_MALFORMED;
         SeqBatch q;
-        q.lit = lit + lit_pos + (xl - (lane < cnt ? my_ll : 0u));
+        const u64 my_lit = lit_pos + (xl - (lane < cnt ? my_ll : 0u));
+        q.lit = lit + my_lit;
         q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = my_off;
+        if (!lit_rle && lit_total != 0) {
+            if (lit_total <= ZSEQ_LWIN && (lit_pos < win_lo || lit_pos + lit_total > win_lo + ZSEQ_LWIN)) {
+                wave_mem_fence();
+                win_lo = lit_pos;
+                const u64 o = win_lo + 16u * (u64)lane;
+                u128 w; w.lo = 0; w.hi = 0;
+                if (o + 16 <= lit_size) w = ld128(lit + o);
+                else for (u64 k = o; k < lit_size && k < o + 16; k++) { const u64 x = (u64)ld8(lit + k); if (k - o < 8) w.lo |= x << (8 * (k - o)); else w.hi |= x << (8 * (k - o - 8)); }
+                lds_st128(lwin + 16u * (u32)lane, w);
+                wave_mem_fence();
+            }
+            if (lane < cnt && my_ll <= SEQ_OWN_MAX && my_lit >= win_lo && my_lit + my_ll <= win_lo + ZSEQ_LWIN) q.lit_lds = (u32)(my_lit - win_lo);
+        }
         SeqStats stt = {};
         (void)stt;
-        const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt);
+        const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt, (lds_cp8)lwin, asm_buf, asm_cap);
         if (rc != D_OK) { a->op = op; return rc; }
         lit_pos += lit_total;
     }
@@ -864,7 +887,7 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         sa.lit = lit; sa.lit_size = lit_size; sa.lit_rle = lit_rle ? 1 : 0; sa.lit_rle_byte = lit_rle_byte;
         sa.op = op; sa.oend = oend; sa.frame_lo = frame_lo; sa.lit_pos = 0;
         sa.deadline = fs.wd->deadline; sa.timed_out = 0; sa.zs = fs.zs;
-        const int src_rc = sa.pre ? zstd_sequences_pre(&sa, lane) : zstd_sequences((ZPK_LDS ZstdShared*)&sh, &sa, lane);
+        const int src_rc = sa.pre ? zstd_sequences_pre((ZPK_LDS ZstdShared*)&sh, &sa, lane) : zstd_sequences((ZPK_LDS ZstdShared*)&sh, &sa, lane);
         if (sa.timed_out) fs.wd->fired = true;
         op = sa.op;
         if (src_rc != D_OK) { produced = (u64)(op - dst); return src_rc; }
