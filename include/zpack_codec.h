@@ -14,6 +14,7 @@
  *        ZSTD_compressCCtx :179 | LZ4F_compressBegin/Update/End         zpk_codec_encode_batch_host
  *        :204-210} + XXH3_64bits :256
  *   lib/zpack_write.c:125-150  zpack_get_compress_bound                 zpk_codec_compress_bound
+ *   lib/zpack_write.c:338      write_offset += comp_size (per file)     zpk_codec_pack_batch_device (scan + compaction)
  *   lib/zpack_read.c:466, lib/zpack_write.c:256  XXH3_64bits            zpk_codec_hash_batch_device / _host
  *   lib/zpack_read.c:17-31,776-812; lib/zpack_write.c:20-34,899-935     zpk_codec_create / _destroy / _reset
  *        ZSTD_createDCtx / LZ4F_createDecompressionContext / ...        (one opaque context for every method)
@@ -128,6 +129,18 @@ int zpk_codec_encode_batch_host(zpk_codec* c, const uint8_t* const* src_ptrs,
                                 const zpk_encode_desc* desc, uint64_t n,
                                 uint8_t* const* dst_ptrs, zpk_encode_result* results);
 
+/* ---- compressed-size scan + compaction (the serial `write_offset += comp_size` of lib/zpack_write.c:338, for a batch)
+ * After an encode batch: offsets[i] = start of entry i's payload in the packed stream (exclusive prefix sum of the
+ * comp_size of the entries with status 0; failed entries take no room), offsets[n] = its total length; when `packed`
+ * is not NULL the payloads are gathered there back-to-back from their slots (`slots` + desc[i].dst_offset), i.e. the
+ * archive's data section in CDR order.  Device pointers, asynchronous on `stream`.  `max_entry_size` = an upper bound
+ * of any comp_size (e.g. the largest dst_capacity); it only sizes the launch.  If packed_cap < offsets[n] the bytes
+ * that do not fit are not written (check offsets[n]). */
+int zpk_codec_pack_batch_device(zpk_codec* c, const uint8_t* slots, const zpk_encode_desc* desc,
+                                const zpk_encode_result* results, uint64_t n,
+                                uint8_t* packed, uint64_t packed_cap, uint64_t* offsets,
+                                uint64_t max_entry_size, void* stream);
+
 /* ---- hash only ---------------------------------------------------------------------------- */
 /* hashes[i] = XXH3_64bits(src + offsets[i], sizes[i]); device pointers, async on stream */
 int zpk_codec_hash_batch_device(zpk_codec* c, const uint8_t* src, const uint64_t* offsets,
@@ -139,7 +152,7 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
 /* per-kernel timing of decode batches: when enabled, every decode batch brackets each of its kernels
  * with HIP events on the launch stream; zpk_codec_kernel_ms then returns the duration of kernel
  * `which` (ZPK_K_*) in the most recent batch (synchronises on that batch). */
-enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2, ZPK_K_ZSTD = 3, ZPK_K_ZSTD_FSE = 4, ZPK_K_COUNT = 5 };
+enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2, ZPK_K_ZSTD = 3, ZPK_K_ZSTD_FSE = 4, ZPK_K_PACK = 5, ZPK_K_COUNT = 6 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
 /* counters of the most recent decode batch (synchronises): out[0..2] = entries on the stored / zstd / lz4 work
  * lists, out[3] = Zstandard entries finished on pre-decoded sequences (two-stage path), out[4] = by the fused decoder,

@@ -200,3 +200,50 @@ def test_zstd_two_stage_path(codec, size, level, n):
         assert out[int(d["dst_offset"]):int(d["dst_offset"] + d["uncomp_size"])].tobytes() == want, i
     assert st["zstd"] == n and st["zstd_two_stage"] + st["zstd_fused"] == n, st
     assert st["zstd_two_stage"] >= (3 * n) // 4, st
+
+
+def test_pack_batch_scan_and_compaction(codec):
+    """K7: after an encode batch the payload offsets are the exclusive prefix sum of the compressed sizes (failed
+    entries take no room) and the packed stream is the concatenation of the slot payloads — what the serial
+    `write_offset += comp_size` loop of lib/zpack_write.c:287-339 lays out."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 3000
+    sizes = rng.integers(0, 9000, n).astype(np.uint64)
+    sizes[::97] = rng.integers(60000, 200000, len(sizes[::97]))
+    methods = rng.integers(0, 3, n).astype(np.uint32)
+    src_off = np.concatenate([[0], np.cumsum((sizes + 31) & ~np.uint64(15))]).astype(np.uint64)
+    blob = dg.fill(dg.TEXT, 9, 0, int(src_off[-1]) + 64)
+    desc = np.zeros(n, dtype=zpack_amd.ENCODE_DESC)
+    caps = np.array([zpack_amd.lib().zpk_codec_compress_bound(int(m), int(s)) for m, s in zip(methods, sizes)], dtype=np.uint64)
+    caps[5::211] = 3                                        # too small on purpose: those entries fail and take no room
+    desc["src_offset"] = src_off[:-1]; desc["size"] = sizes; desc["method"] = methods; desc["level"] = 1
+    desc["dst_offset"] = np.concatenate([[0], np.cumsum((caps + 63) & ~np.uint64(15))])[:-1]; desc["dst_capacity"] = caps
+    slots_bytes = int(desc["dst_offset"][-1] + caps[-1]) + 64
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(blob).to(dev)
+    slots = torch.zeros(slots_bytes, dtype=torch.uint8, device=dev)
+    ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    dres = torch.zeros(n * zpack_amd.ENCODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+    codec.encode_batch_device(src, ddesc, n, slots, dres)
+    offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    packed = torch.full((slots_bytes,), 0xEE, dtype=torch.uint8, device=dev)
+    codec.pack_batch_device(slots, ddesc, dres, n, packed, offs, int(caps.max()))
+    torch.cuda.synchronize()
+    res = dres.cpu().numpy().view(zpack_amd.ENCODE_RESULT)
+    ok = res["status"] == 0
+    assert (~ok).sum() >= 5 and ok.sum() > n - 40
+    want_sizes = np.where(ok, res["comp_size"], 0).astype(np.uint64)
+    want_off = np.concatenate([[0], np.cumsum(want_sizes)]).astype(np.uint64)
+    got_off = offs.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got_off, want_off)
+    hs, hp = slots.cpu().numpy(), packed.cpu().numpy()
+    for i in range(n):
+        a = int(desc["dst_offset"][i]); k = int(want_sizes[i])
+        assert np.array_equal(hp[int(want_off[i]):int(want_off[i]) + k], hs[a:a + k]), i
+    assert (hp[int(want_off[-1]):int(want_off[-1]) + 64] == 0xEE).all()       # nothing past the end
+    # sizes only
+    offs2 = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    codec.pack_batch_device(slots, ddesc, dres, n, None, offs2, int(caps.max()))
+    torch.cuda.synchronize()
+    assert np.array_equal(offs2.cpu().numpy().view(np.uint64), want_off)

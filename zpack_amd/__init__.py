@@ -16,7 +16,7 @@ ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
 
 METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
-K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE = 0, 1, 2, 3, 4
+K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK = 0, 1, 2, 3, 4, 5
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
 DECODE_DESC = np.dtype([("src_offset", "<u8"), ("comp_size", "<u8"), ("uncomp_size", "<u8"), ("expect_hash", "<u8"),
@@ -60,6 +60,7 @@ def lib():
         L.zpk_codec_decode_batch_host.argtypes = [vp, u8p, u64, vp, u64, vp, vp]
         L.zpk_codec_encode_batch_device.argtypes = [vp, u8p, u64, vp, u64, u8p, u64, vp, vp]
         L.zpk_codec_encode_batch_host.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.zpk_codec_pack_batch_device.argtypes = [vp, u8p, vp, vp, u64, u8p, u64, vp, u64, vp]
         L.zpk_codec_compress_bound.argtypes = [C.c_uint32, C.c_size_t]
         L.zpk_codec_compress_bound.restype = C.c_size_t
         L.zpk_codec_hash_batch_device.argtypes = [vp, u8p, vp, vp, u64, vp, vp]
@@ -115,6 +116,14 @@ class Codec:
         self._chk(self.L.zpk_codec_encode_batch_device(self.h, src.data_ptr(), src.numel(), desc_dev.data_ptr(), n,
                                                        dst.data_ptr(), dst.numel(), results_dev.data_ptr(), st),
                   "zpk_codec_encode_batch_device")
+
+    def pack_batch_device(self, slots, desc_dev, results_dev, n, packed, offsets_dev, max_entry_size, stream=None):
+        """offsets_dev: int64 CUDA tensor of n + 1; packed: uint8 CUDA tensor or None (sizes only)."""
+        st = C.c_void_p(stream) if stream else None
+        self._chk(self.L.zpk_codec_pack_batch_device(self.h, slots.data_ptr(), desc_dev.data_ptr(), results_dev.data_ptr(), n,
+                                                     packed.data_ptr() if packed is not None else None,
+                                                     packed.numel() if packed is not None else 0, offsets_dev.data_ptr(),
+                                                     max_entry_size, st), "zpk_codec_pack_batch_device")
 
     def hash_batch_device(self, src, offsets_dev, sizes_dev, n, hashes_dev, stream=None):
         st = C.c_void_p(stream) if stream else None

@@ -280,6 +280,9 @@ struct zpk_codec {
     void* d_res = nullptr;       u64 res_cap = 0;
     u64* d_dbg = nullptr;        u64 dbg_cap = 0;
     u64* d_seq = nullptr;        u64 seq_cap = 0;      // encoder: sequence lists, one per workgroup
+    u8*  d_pack = nullptr;       u64 pack_cap = 0;     // K7: block sums + span index of the compaction
+    u8*  d_packed = nullptr;     u64 packed_cap = 0;   // host encode path: packed payload stream
+    u8*  d_packoff = nullptr;    u64 packoff_cap = 0;  // host encode path: payload offsets
     u64* d_zarena = nullptr;     u64 zarena_cap = 0;   // decoder: pre-decoded Zstandard sequences, laid out like dst (zstd_fse4.h)
     u32* d_zstate = nullptr;     u64 zstate_cap = 0;   // decoder: per entry, 1 = its sequences are in the arena
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -345,7 +348,7 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     (void)hipFree(c->d_counters); (void)hipFree(c->d_lists); (void)hipFree(c->d_lit);
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
-    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate);
+    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_pack); (void)hipFree(c->d_packed); (void)hipFree(c->d_packoff);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
