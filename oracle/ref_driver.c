@@ -27,6 +27,10 @@ static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 static void* run(void* arg)
 {
     job_t* j = (job_t*)arg;
+    /* every thread reads through its own shallow copy of the (memory-shared) reader: zpack_read_file stores the codec's
+     * return value in reader->last_return and the LZ4 path reads it back (lib/zpack_read.c:419-450), so one shared
+     * struct makes concurrent readers see each other's values (spurious FILE_INCOMPLETE on mixed archives) */
+    zpack_reader local = *j->reader;
     void* zd = zpack_create_dctx(ZPACK_COMPRESSION_ZSTD);
     void* ld = zpack_create_dctx(ZPACK_COMPRESSION_LZ4);
     uint64_t cap = 0;
@@ -35,9 +39,9 @@ static void* run(void* arg)
     double t0 = now();
     do {
         for (uint64_t i = j->lo; i < j->hi; i++) {
-            zpack_file_entry* e = &j->reader->file_entries[i];
+            zpack_file_entry* e = &local.file_entries[i];
             void* d = e->comp_method == ZPACK_COMPRESSION_ZSTD ? zd : (e->comp_method == ZPACK_COMPRESSION_LZ4 ? ld : NULL);
-            int rc = zpack_read_file(j->reader, e, buf, cap, d);      /* decode + XXH3 verify, lib/zpack_read.c:326-471 */
+            int rc = zpack_read_file(&local, e, buf, cap, d);      /* decode + XXH3 verify, lib/zpack_read.c:326-471 */
             if (rc) j->errors++;
             j->bytes += e->uncomp_size; j->entries++;
         }

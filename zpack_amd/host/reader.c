@@ -138,6 +138,58 @@ int zpack_read_cdr(FILE* fp, zpack_u64 cdr_offset, zpack_file_entry** entries, z
     return rc;
 }
 
+/* CDR -> reader-owned entry table, with ALL filenames in one allocation (at 1 M entries the
+ * reference's malloc + memcpy per name, lib/zpack_read.c:109-134, is the visible serial cost once decode is fast).
+ * The arena hangs off reader->lz4f_dctx, a field this implementation has no other use for; zpack_close_reader frees
+ * it instead of the individual names.  The public zpack_read_cdr* / zpack_read_file_entries_memory keep the
+ * reference's one-malloc-per-name contract for callers that own their tables. */
+static int reader_load_entries(zpack_reader* reader, const zpack_u8* cdr, size_t size_left)
+{
+    zpack_u64 n = 0, block = 0;
+    int rc = zpack_read_cdr_header_memory(cdr, &n, &block);
+    if (rc) return rc;
+    if (block > (zpack_u64)size_left || ZPACK_CDR_HEADER_SIZE + block > (zpack_u64)size_left) return ZPACK_ERROR_BLOCK_SIZE_INVALID;
+    if (n == 0) return ZPACK_OK;
+    if (n > block / ZPACK_FILE_ENTRY_FIXED_SIZE) return ZPACK_ERROR_BLOCK_SIZE_INVALID;
+    if (n > SIZE_MAX / sizeof(zpack_file_entry)) return ZPACK_ERROR_MALLOC_FAILED;
+    const zpack_u8* const body = cdr + ZPACK_CDR_HEADER_SIZE;
+    /* pass 1: record sizes (the same checks, in the same order, as the record-by-record parser) */
+    zpack_u64 left = block, names = 0;
+    const zpack_u8* p = body;
+    for (zpack_u64 i = 0; i < n; i++) {
+        if (left < 2) return ZPACK_ERROR_BLOCK_SIZE_INVALID;
+        const zpack_u64 rec = (zpack_u64)ZPACK_FILE_ENTRY_FIXED_SIZE + zi_get16(p);
+        if (rec > left) return ZPACK_ERROR_BLOCK_SIZE_INVALID;
+        names += (zpack_u64)zi_get16(p) + 1;
+        left -= rec; p += rec;
+    }
+    zpack_file_entry* table = (zpack_file_entry*)realloc(reader->file_entries, sizeof(zpack_file_entry) * (size_t)n);
+    char* arena = (char*)malloc((size_t)names);
+    if (!table || !arena) { free(arena); if (table) reader->file_entries = table; return ZPACK_ERROR_MALLOC_FAILED; }
+    reader->file_entries = table;
+    reader->lz4f_dctx = arena;
+    /* pass 2 */
+    p = body;
+    char* w = arena;
+    for (zpack_u64 i = 0; i < n; i++) {
+        const zpack_u16 nlen = zi_get16(p);
+        zpack_file_entry* e = table + i;
+        e->filename = w;
+        memcpy(w, p + 2, nlen); w[nlen] = '\0'; w += (size_t)nlen + 1;
+        const zpack_u8* f = p + 2 + nlen;
+        e->offset = zi_get64(f);
+        e->comp_size = zi_get64(f + 8);
+        e->uncomp_size = zi_get64(f + 16);
+        e->hash = zi_get64(f + 24);
+        e->comp_method = f[32];
+        reader->comp_size += e->comp_size;
+        reader->uncomp_size += e->uncomp_size;
+        p = f + 33;
+    }
+    reader->file_count += n;
+    return ZPACK_OK;
+}
+
 int zpack_read_archive_memory(zpack_reader* reader)
 {
     if (!reader->buffer) return ZPACK_ERROR_ARCHIVE_NOT_LOADED;
@@ -149,8 +201,10 @@ int zpack_read_archive_memory(zpack_reader* reader)
     reader->eocdr_offset = reader->file_size - ZPACK_EOCDR_SIZE;
     if ((rc = zpack_read_eocdr_memory(a + reader->eocdr_offset, &reader->cdr_offset))) return rc;
     if (reader->cdr_offset >= reader->file_size) return ZPACK_ERROR_READ_FAILED;
-    return zpack_read_cdr_memory(a + reader->cdr_offset, reader->file_size - (size_t)reader->cdr_offset, &reader->file_entries,
-                                 &reader->file_count, &reader->comp_size, &reader->uncomp_size);
+    if (reader->file_entries || reader->lz4f_dctx)        /* a table from an earlier (public-API) parse: keep its contract */
+        return zpack_read_cdr_memory(a + reader->cdr_offset, reader->file_size - (size_t)reader->cdr_offset, &reader->file_entries,
+                                     &reader->file_count, &reader->comp_size, &reader->uncomp_size);
+    return reader_load_entries(reader, a + reader->cdr_offset, reader->file_size - (size_t)reader->cdr_offset);
 }
 
 int zpack_read_archive(zpack_reader* reader)
@@ -164,8 +218,24 @@ int zpack_read_archive(zpack_reader* reader)
     if ((rc = zpack_read_data_header(reader->file))) return rc;
     reader->eocdr_offset = reader->file_size - ZPACK_EOCDR_SIZE;
     if ((rc = zpack_read_eocdr(reader->file, reader->eocdr_offset, &reader->cdr_offset))) return rc;
-    return zpack_read_cdr(reader->file, reader->cdr_offset, &reader->file_entries, &reader->file_count,
-                          &reader->comp_size, &reader->uncomp_size);
+    if (reader->file_entries || reader->lz4f_dctx)
+        return zpack_read_cdr(reader->file, reader->cdr_offset, &reader->file_entries, &reader->file_count,
+                              &reader->comp_size, &reader->uncomp_size);
+    {   /* the whole CDR in one read, then the arena parse */
+        zpack_u8 hdr[ZPACK_CDR_HEADER_SIZE];
+        if ((rc = read_at(reader->file, reader->cdr_offset, hdr, sizeof(hdr)))) return rc;
+        zpack_u64 n = 0, block = 0;
+        if ((rc = zpack_read_cdr_header_memory(hdr, &n, &block))) return rc;
+        if (n == 0) return ZPACK_OK;
+        if (block > SIZE_MAX - ZPACK_CDR_HEADER_SIZE) return ZPACK_ERROR_MALLOC_FAILED;
+        zpack_u8* cdr = (zpack_u8*)malloc(ZPACK_CDR_HEADER_SIZE + (size_t)block);
+        if (!cdr) return ZPACK_ERROR_MALLOC_FAILED;
+        memcpy(cdr, hdr, sizeof(hdr));
+        if (block && fread(cdr + ZPACK_CDR_HEADER_SIZE, (size_t)block, 1, reader->file) != 1) { free(cdr); return ZPACK_ERROR_READ_FAILED; }
+        rc = reader_load_entries(reader, cdr, ZPACK_CDR_HEADER_SIZE + (size_t)block);
+        free(cdr);
+        return rc;
+    }
 }
 
 /* ------------------------------------------------------------------ raw (still compressed) access */
@@ -393,9 +463,11 @@ void zpack_close_reader(zpack_reader* reader)
     if (reader->file) fclose(reader->file);
     if (!reader->buffer_shared) free(reader->buffer);
     if (reader->file_entries) {
-        for (zpack_u64 i = 0; i < reader->file_count; i++) free(reader->file_entries[i].filename);
+        if (!reader->lz4f_dctx)                                /* names in one arena (reader_load_entries) or one malloc each */
+            for (zpack_u64 i = 0; i < reader->file_count; i++) free(reader->file_entries[i].filename);
         free(reader->file_entries);
     }
+    free(reader->lz4f_dctx);
     if (reader->zstd_dctx) zpk_codec_destroy((zpk_codec*)reader->zstd_dctx);
     memset(reader, 0, sizeof(*reader));
 }
