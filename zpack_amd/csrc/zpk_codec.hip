@@ -27,7 +27,7 @@ using namespace zpk;
 // counters layout (u32): [0..3] count per work list, [4..7] dequeue head per list
 enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4, N_LISTS = 3 };
 // [8] dequeue head of k_zstd_fse, [9] Zstandard entries finished on pre-decoded sequences, [10] finished by the fused decoder
-enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10 };
+enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, N_COUNTERS = 32 };
 
 // ------------------------------------------------------------------------------------ kernels
 
@@ -191,11 +191,66 @@ __global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, 
     }
 }
 
+// Stage 2 of the two-stage Zstandard path: entries whose sequences k_zstd_fse left in the arena (zstate == 1) are run
+// here — Huffman literals, execution, XXH3 — by a kernel that carries neither the FSE decoder's code nor its tables:
+// 9.4 KiB of LDS and <= 128 VGPRs, 16 workgroups per CU instead of 12.  Only a VERIFIED entry is finished here
+// (result written, zstate = 2); everything else is left to k_zstd, so the verdict of every entry that is not
+// byte-exact with its checksum is always the full decoder's.
+#define ZSTD_EXEC_GRID_MAX 4096
+__global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
+                                                               u8* dst, zpk_decode_result* __restrict__ res,
+                                                               const u32* __restrict__ list, u32* __restrict__ counters,
+                                                               u8* __restrict__ lit_scratch, const u64* __restrict__ arena,
+                                                               u32* __restrict__ zstate)
+{
+    const int lane = lane_id();
+    __shared__ __attribute__((aligned(16))) u8 sh_raw[ZSTD_SHARED_EXEC_BYTES];
+    ZstdShared& sh = *(ZstdShared*)sh_raw;
+    if (threadIdx.x == 0) { sh.defaults_built = 0; sh.huf_valid = 0; }
+    __syncthreads();
+    u8* lit = lit_scratch + (u64)blockIdx.x * ZSTD_LIT_SCRATCH;
+    const u32 nz = uni(counters[L_ZSTD]);
+    for (;;) {
+        lane0_guard();
+        u32 v = 0;
+        if (lane == 0) v = atomicAdd(&counters[C_EXEC_HEAD], 1u);
+        const u32 idx = uni(v);
+        lane0_guard();
+        if (idx >= nz) break;
+        const u32 e = uni(list[idx]);
+        if (uni(zstate[e]) != 1u) continue;
+        const zpk_decode_desc d = desc[e];
+        const u8* in = uni_ptr(src + d.src_offset);
+        u8* out = uni_ptr(dst + d.dst_offset);
+        const u64* const pre = arena + (((u64)d.dst_offset + 7) >> 3);
+        Watchdog wd; wd.arm();
+        DecodeOut o = zstd_decode_wave<true>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, nullptr, pre);
+        bool ok = o.rc == D_OK;
+        u64 h = 0;
+        lane0_guard();
+        if (ok && !(d.flags & ZPK_DF_SKIP_HASH)) {
+            wave_mem_fence();
+            h = xxh3_64_wave(out, d.uncomp_size, lane);                            // lib/zpack_read.c:466
+            ok = h == d.expect_hash;
+        }
+        lane0_guard();
+        if (lane == 0) {
+            if (ok) {
+                zpk_decode_result r; r.status = R_OK; r.detail = 0; r.produced = o.produced; r.hash = h;
+                res[e] = r;
+                zstate[e] = 2u;
+                atomicAdd(&counters[C_ZSTD_TWO_STAGE], 1u);
+            } else { atomicAdd(&counters[14], 1u); counters[15] = ((u32)(ok ? 0 : 1) << 16) | ((u32)(-o.rc) & 0xFFFFu); }
+        }
+    }
+}
+
+// the full decoder: every Zstandard entry the two-stage path did not finish (all of them when it is off)
 __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                           u8* dst, zpk_decode_result* __restrict__ res,
                                                           const u32* __restrict__ list, u32* __restrict__ counters,
                                                           u8* __restrict__ lit_scratch, u64* __restrict__ dbg,
-                                                          const u64* __restrict__ arena, const u32* __restrict__ zstate)
+                                                          const u32* __restrict__ zstate)
 {
     const int lane = lane_id();
     __shared__ ZstdShared sh;
@@ -205,51 +260,27 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restric
     u32 idx;
     while (dequeue(counters, L_ZSTD, lane, idx)) {
         const u32 e = uni(list[idx]);
+        if (zstate != nullptr && uni(zstate[e]) == 2u) continue;
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
-        // Pass 0 runs on the sequences k_zstd_fse left in the arena (zstd_fse4.h) when it marked the entry; whenever that
-        // pass does not end in a verified entry, pass 1 decodes the entry in full, so the verdict is always the fused
-        // decoder's.
-        const bool marked = zstate != nullptr && uni(zstate[e]) == 1u;
-        const u64* const pre = arena + (((u64)d.dst_offset + 7) >> 3);
-        #pragma unroll 1
-        for (int pass = marked ? 0 : 1; pass < 2; pass++) {
-            Watchdog wd; wd.arm();
+        Watchdog wd; wd.arm();
 #ifdef ZPK_STATS
-            ZstdStats zs = {};
-            const u64 t_all = SEQ_T();
-            DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, &zs, pass == 0 ? pre : nullptr);
-            if (dbg && lane == 0) {
-                u64* g = dbg + (u64)e * 8;
-                g[0] = zs.t_lit; g[1] = zs.t_tab; g[2] = zs.t_fse; g[3] = zs.t_exec; g[4] = zs.nseq; g[5] = zs.nblk; g[6] = SEQ_T() - t_all; g[7] = (u64)pass;
-            }
-#else
-            (void)dbg;
-            DecodeOut o = zstd_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, nullptr, pass == 0 ? pre : nullptr);
-#endif
-            int status = o.rc == D_OK ? R_OK : R_DECOMPRESS_FAILED;               // lib/zpack_read.c:384-388
-            u64 h = 0;
-            lane0_guard();
-            if (status == R_OK && !(d.flags & ZPK_DF_SKIP_HASH)) {
-                wave_mem_fence();
-                h = xxh3_64_wave(out, d.uncomp_size, lane);                        // lib/zpack_read.c:466
-                if (h != d.expect_hash) status = R_FILE_HASH_MISMATCH;             // :467-468
-            }
-            if (pass == 0 && status != R_OK) {
-                lane0_guard();
-                if (lane == 0) { atomicAdd(&counters[14], 1u); counters[15] = ((u32)status << 16) | ((u32)(-o.rc) & 0xFFFFu); }
-                lane0_guard();
-                continue;
-            }
-            lane0_guard();
-            if (lane == 0) {
-                zpk_decode_result r; r.status = status; r.detail = wd.fired ? 0xDEADu : (u32)(-o.rc); r.produced = o.produced; r.hash = h;
-                res[e] = r;
-                atomicAdd(&counters[pass == 0 ? C_ZSTD_TWO_STAGE : C_ZSTD_FUSED], 1u);
-            }
-            break;
+        ZstdStats zs = {};
+        const u64 t_all = SEQ_T();
+        DecodeOut o = zstd_decode_wave<false>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, &zs);
+        if (dbg && lane == 0) {
+            u64* g = dbg + (u64)e * 8;
+            g[0] = zs.t_lit; g[1] = zs.t_tab; g[2] = zs.t_fse; g[3] = zs.t_exec; g[4] = zs.nseq; g[5] = zs.nblk; g[6] = SEQ_T() - t_all; g[7] = 0;
         }
+#else
+        (void)dbg;
+        DecodeOut o = zstd_decode_wave<false>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane);
+#endif
+        int status = o.rc == D_OK ? R_OK : R_DECOMPRESS_FAILED;               // lib/zpack_read.c:384-388
+        finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
+        lane0_guard();
+        if (lane == 0) atomicAdd(&counters[C_ZSTD_FUSED], 1u);
     }
 }
 
@@ -332,7 +363,7 @@ int zpk_codec_create(zpk_codec** out, int device)
     if (!c) return ZPK_E_NOMEM;
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, 64) != hipSuccess ||
+        hipMalloc((void**)&c->d_counters, N_COUNTERS * sizeof(u32)) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return ZPK_E_NO_DEVICE;
@@ -370,7 +401,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     static const int want_dbg = getenv("ZPK_DEBUG_TIMING") ? atoi(getenv("ZPK_DEBUG_TIMING")) : 0;
     if (want_dbg) { if ((rc = grow(c, (void**)&c->d_dbg, &c->dbg_cap, n * 64))) return rc; }
     const u32 zstd_grid = (u32)(n < ZSTD_GRID_MAX ? n : ZSTD_GRID_MAX);
-    if ((rc = grow(c, (void**)&c->d_lit, &c->lit_cap, (u64)ZSTD_GRID_MAX * ZSTD_LIT_SCRATCH))) return rc;
+    if ((rc = grow(c, (void**)&c->d_lit, &c->lit_cap, (u64)ZSTD_EXEC_GRID_MAX * ZSTD_LIT_SCRATCH))) return rc;
     // debugging aids: ZPK_TRACE=1 synchronises and reports after every launch, ZPK_SKIP=<bitmask> leaves
     // kernels out (1 stored, 2 lz4, 4 zstd)
     static const int trace = getenv("ZPK_TRACE") ? atoi(getenv("ZPK_TRACE")) : 0;
@@ -380,7 +411,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
 #define ZPK_TRACE_STEP(name) do { if (trace == 1) { hipError_t te_ = hipStreamSynchronize(st); \
         fprintf(stderr, "[zpk] %s done: %s\n", name, hipGetErrorString(te_)); fflush(stderr); } \
         else if (trace == 2) { tev_name[tev_n] = name; (void)hipEventRecord(tev[tev_n++], st); } } while (0)
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 64, st));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(u32), st));
     ZPK_TRACE_STEP("memset");
 #define ZPK_KEV(k, j) do { if (c->profiling) (void)hipEventRecord(c->kev[k][j], st); } while (0)
     ZPK_KEV(ZPK_K_CLASSIFY, 0);
@@ -415,9 +446,11 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_KEV(ZPK_K_ZSTD_FSE, 1);
     ZPK_TRACE_STEP("k_zstd_fse");
     ZPK_KEV(ZPK_K_ZSTD, 0);
+    if (!(skip & 4) && two_stage)
+        hipLaunchKernelGGL(k_zstd_exec, dim3((u32)(n < ZSTD_EXEC_GRID_MAX ? n : ZSTD_EXEC_GRID_MAX)), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
+                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_zarena, c->d_zstate);
     if (!(skip & 4)) hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
-                       c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_dbg,
-                       two_stage ? c->d_zarena : (const u64*)nullptr, two_stage ? c->d_zstate : (const u32*)nullptr);
+                       c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_dbg, two_stage ? c->d_zstate : (const u32*)nullptr);
     ZPK_KEV(ZPK_K_ZSTD, 1);
     ZPK_TRACE_STEP("k_zstd");
     if (trace == 2) {
@@ -554,7 +587,7 @@ int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8])
     if (!c || !out) return ZPK_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
-    u32 h[16];
+    u32 h[N_COUNTERS];
     HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[L_NONE]; out[1] = h[L_ZSTD]; out[2] = h[L_LZ4]; out[3] = h[C_ZSTD_TWO_STAGE]; out[4] = h[C_ZSTD_FUSED];
     out[5] = h[ZF_WATCHDOG_WORD]; out[6] = h[ZF_WATCHDOG_WORD + 1]; out[7] = h[13];

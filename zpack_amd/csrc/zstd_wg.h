@@ -38,11 +38,9 @@ __device__ __forceinline__ u32 cell_nb(FseCell c)   { return (c >> 10) & 15u; }
 __device__ __forceinline__ u32 cell_add(FseCell c)  { return (c >> 14) & 31u; }
 __device__ __forceinline__ u32 cell_sym(FseCell c)  { return (c >> 19) & 63u; }
 
+// The members the FSE sequence decoder alone needs come LAST: the execute-only kernel (k_zstd_exec, entries whose
+// sequences k_zstd_fse has already decoded) allocates just ZSTD_SHARED_EXEC_BYTES of this layout.
 struct alignas(16) ZstdShared {
-    FseCell ll[512], ml[512], of[256];
-    FseCell dll[64], dml[64], dof[32];           // predefined distributions (built once per workgroup)
-    u32 symtab_ll[36], symtab_ml[54];            // literal-length / match-length codes: baseline | extra bits << 24
-    u32 ofbase[32];                              // offset codes: 1 << code
     u8  huf[4096];                               // symbol of every max_bits-bit prefix (the code length follows from huf_rank)
     u32 huf_rank[16];                            // [w] first table index of weight class w (1..max_bits), ~0 above: nbits = max_bits + 1 - w
     union {
@@ -59,7 +57,15 @@ struct alignas(16) ZstdShared {
     u32 huf_max_bits;
     u32 huf_valid;
     u32 defaults_built;
+    u32 pad_;
+    // ---- FSE decode (full decoder); its first bytes double as the executor's assembly buffer + literal window ----
+    FseCell ll[512], ml[512], of[256];
+    FseCell dll[64], dml[64], dof[32];           // predefined distributions (built once per workgroup)
+    u32 symtab_ll[36], symtab_ml[54];            // literal-length / match-length codes: baseline | extra bits << 24
+    u32 ofbase[32];                              // offset codes: 1 << code
 };
+#define ZSTD_EXEC_WORK 2592u                     // execute-only kernel: 1536 B of batch assembly + the literal window
+#define ZSTD_SHARED_EXEC_BYTES (__builtin_offsetof(ZstdShared, ll) + ZSTD_EXEC_WORK)
 
 __device__ __constant__ const u32 Z_LL_BASE[36] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,
                                                      0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000 };
@@ -598,6 +604,7 @@ struct ZSeqArgs {
     u64 deadline; int timed_out;
     ZstdStats* zs;
     const u64* pre;                       // this block's sequences, packed (zstd_fse4.h), when pre-decoded
+    u32 work_bytes;                       // pre-decoded: bytes of LDS at sh->ll the executor may use
 };
 
 // The same section when k_zstd_fse has already decoded it: 64 packed sequences per load, then execution.
@@ -607,8 +614,9 @@ __device__ __noinline__ int zstd_sequences_pre(ZPK_LDS ZstdShared* sh, ZSeqArgs*
     // and as a 1 KiB window over the literal stream, refilled with one coalesced load when a batch leaves it, so that
     // literal runs are read with ds_read_b128 instead of up to four exact-tail vector loads per lane
     const lds_p8 asm_buf = (lds_p8)sh->ll;
-    const u32 asm_cap = 4096u - 64u;
-    const lds_p8 lwin = asm_buf + 4096u - 32u;            // ZSEQ_LWIN bytes + 16 of read slack, inside the 5 KiB
+    const u32 work = (u32)__builtin_amdgcn_readfirstlane((int)a->work_bytes);          // >= ZSEQ_LWIN + 16 + 64 + a useful assembly size
+    const u32 asm_cap = work - (ZSEQ_LWIN + 16u) - 16u;
+    const lds_p8 lwin = asm_buf + (work - (ZSEQ_LWIN + 16u));                          // ZSEQ_LWIN bytes + 16 of read slack
     u64 win_lo = ~0ull;
     const u64 nseq = uni64(a->nseq);
     const u64* const pre = uni_ptr(a->pre);
@@ -785,6 +793,7 @@ __device__ __noinline__ int zstd_sequences(ZPK_LDS ZstdShared* sh, ZSeqArgs* a, 
     return D_OK;
 }
 
+template <bool EXEC_ONLY>
 __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src, u64 size, const u8* rd_hi,
                                  u8* dst, u64 dst_cap, u8* frame_lo, u8* lit_buf, u64& produced, int lane)
 {
@@ -843,11 +852,13 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         if (left < 1) return D_MALFORMED;
         ZSeqArgs sa;
         sa.pre = nullptr;
-        if (fs.pre) {
+        sa.work_bytes = EXEC_ONLY ? ZSTD_EXEC_WORK : 5120u;
+        if (EXEC_ONLY || fs.pre) {
             // k_zstd_fse has validated the tables and the bitstream of this block and decoded it
             sa.pre = fs.pre + fs.pre_idx;
             fs.pre_idx += nseq;
-        } else {
+        }
+        if constexpr (!EXEC_ONLY) if (!fs.pre) {
         const u32 modes = uld8(p);
         p += 1; left -= 1;
         int pending = 0, ns[3] = {0, 0, 0};
@@ -887,7 +898,9 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         sa.lit = lit; sa.lit_size = lit_size; sa.lit_rle = lit_rle ? 1 : 0; sa.lit_rle_byte = lit_rle_byte;
         sa.op = op; sa.oend = oend; sa.frame_lo = frame_lo; sa.lit_pos = 0;
         sa.deadline = fs.wd->deadline; sa.timed_out = 0; sa.zs = fs.zs;
-        const int src_rc = sa.pre ? zstd_sequences_pre((ZPK_LDS ZstdShared*)&sh, &sa, lane) : zstd_sequences((ZPK_LDS ZstdShared*)&sh, &sa, lane);
+        int src_rc;
+        if constexpr (EXEC_ONLY) src_rc = zstd_sequences_pre((ZPK_LDS ZstdShared*)&sh, &sa, lane);
+        else src_rc = sa.pre ? zstd_sequences_pre((ZPK_LDS ZstdShared*)&sh, &sa, lane) : zstd_sequences((ZPK_LDS ZstdShared*)&sh, &sa, lane);
         if (sa.timed_out) fs.wd->fired = true;
         op = sa.op;
         if (src_rc != D_OK) { produced = (u64)(op - dst); return src_rc; }
@@ -926,6 +939,7 @@ __device__ inline void zstd_build_defaults(ZstdShared& sh, int lane)
     __syncthreads();
 }
 
+template <bool EXEC_ONLY = false>
 __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u8* lit_buf, int lane,
                                              ZstdStats* zs = nullptr, const u64* pre = nullptr)
 {
@@ -933,7 +947,7 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const
     DecodeOut r; r.rc = D_OK; r.produced = 0;
     const u8* ip = src; const u8* iend = src + src_size;
     u8* op = dst; u8* oend = dst + dst_cap;
-    if (!sh.defaults_built) { zstd_build_defaults(sh, lane); sh.defaults_built = 1; }
+    if constexpr (!EXEC_ONLY) if (!sh.defaults_built) { zstd_build_defaults(sh, lane); sh.defaults_built = 1; }
     __syncthreads();
 
     while (ip < iend) {
@@ -1002,7 +1016,7 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const
             } else {
                 if (bsize > (u64)(iend - ip) || bsize >= ZSTD_BLOCK_MAX) { r.rc = D_MALFORMED; fail = true; break; }
                 u64 got = 0;
-                int rc = zstd_block(sh, fs, ip, bsize, iend, op, (u64)(oend - op), frame_lo, lit_buf, got, lane);
+                int rc = zstd_block<EXEC_ONLY>(sh, fs, ip, bsize, iend, op, (u64)(oend - op), frame_lo, lit_buf, got, lane);
                 if (rc != D_OK) { r.rc = rc; fail = true; break; }
                 ip += bsize; op += got;
             }
