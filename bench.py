@@ -177,13 +177,17 @@ def main():
               file=sys.stderr)
 
     # ---- dominant-kernel time, HIP events on the launch stream ----
-    kid = dict(lz4=zpack_amd.K_LZ4, zstd=zpack_amd.K_ZSTD, stored=zpack_amd.K_STORED)[w["kernel"]]
+    # (Zstandard runs as a pipeline: k_zstd_fse pre-decodes the sequence streams, k_zstd_exec + k_zstd do the rest;
+    # its figure is the sum of the stages, bracketed on the stream one after the other)
+    kids = dict(lz4=[zpack_amd.K_LZ4], zstd=[zpack_amd.K_ZSTD_FSE, zpack_amd.K_ZSTD], stored=[zpack_amd.K_STORED])[w["kernel"]]
     codec.set_profiling(True)
-    kms = []
+    kms, stage_ms = [], None
     for _ in range(max(3, min(args.steps, 10))):
         step()
-        kms.append(codec.kernel_ms(kid))
+        stage_ms = [codec.kernel_ms(k) for k in kids]
+        kms.append(sum(stage_ms))
     codec.set_profiling(False)
+    dstats = codec.decode_stats()
     k_ms = float(np.mean(kms))
     alg_bytes = float(batch.total_comp + batch.total_uncomp)            # each byte moved once
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
@@ -192,18 +196,19 @@ def main():
     # figure comes from the committed rocprofv3 --pmc summary of THIS workload at THIS size (tools/pmc.sh,
     # separate FETCH_SIZE / WRITE_SIZE passes); null when no matching measurement is committed.
     traffic, traffic_note = None, "no committed PMC summary for this workload/size"
-    kname = {"lz4": "k_lz4_wave", "zstd": "k_zstd", "stored": "k_stored"}[w["kernel"]]
+    knames = {"lz4": ["k_lz4_wave"], "zstd": ["k_zstd_fse", "k_zstd_exec", "k_zstd"], "stored": ["k_stored"]}[w["kernel"]]
+    kname = "+".join(knames)
     try:
         for rd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             f = os.path.join(ROOT, "profiles", rd, "pmc_%s.json" % args.workload)
             if os.path.exists(f):
                 pm = json.load(open(f))
-                if pm.get("entries_per_gpu") == n and kname in pm.get("kernels", {}):
-                    k = pm["kernels"][kname]
+                ks = [pm["kernels"][x] for x in knames if x in pm.get("kernels", {})]
+                if pm.get("entries_per_gpu") == n and ks:
                     # MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts 64 B per 128-B request on gfx950 (x2); WRITE_SIZE is exact
-                    traffic = 2.0 * k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"]
-                    traffic_note = "%s: 2 x FETCH_SIZE (%.3g B raw) + WRITE_SIZE (%.3g B), mean per launch" % (
-                        os.path.relpath(f, ROOT), k["FETCH_SIZE_bytes"], k["WRITE_SIZE_bytes"])
+                    fs, ws = sum(k["FETCH_SIZE_bytes"] for k in ks), sum(k["WRITE_SIZE_bytes"] for k in ks)
+                    traffic = 2.0 * fs + ws
+                    traffic_note = "%s: 2 x FETCH_SIZE (%.3g B raw) + WRITE_SIZE (%.3g B), mean per launch" % (os.path.relpath(f, ROOT), fs, ws)
                 break
     except Exception as ex:
         traffic_note = "PMC summary unreadable: %s" % ex
@@ -235,7 +240,8 @@ def main():
             "event_ms_per_step": ev_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note, "kernel": kname,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms": k_ms, "stage_ms": stage_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "decode_stats": dstats,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -31,6 +31,20 @@ for cls, cname in enumerate(["text", "records", "random", "runs"]):
             torch.cuda.synchronize(); t = time.perf_counter()
             codec.encode_batch_device(src, ddesc, n, dst, dres)
             torch.cuda.synchronize(); dt = time.perf_counter() - t
+        # K7: scan of the compressed sizes + compaction of the payloads into one packed stream
+        offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        packed = torch.empty(int(n * bound), dtype=torch.uint8, device=dev)
+        codec.set_profiling(True)
+        for it in range(3):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            codec.pack_batch_device(dst, ddesc, dres, n, packed, offs, int(bound))
+            torch.cuda.synchronize(); dtp = time.perf_counter() - t
+        gather_ms = codec.kernel_ms(zpack_amd.K_PACK)
+        codec.set_profiling(False)
+        total_c = int(offs[-1].item())
         res = dres.cpu().numpy().view(zpack_amd.ENCODE_RESULT)
+        assert total_c == int(res["comp_size"][res["status"] == 0].sum())
+        print("         pack: %.3f ms wall, k_pack_gather %.3f ms = %.0f GB/s (read + write of %.2f GB packed)" %
+              (dtp * 1e3, gather_ms, 2 * total_c / (gather_ms * 1e-3) / 1e9, total_c / 1e9), flush=True)
         ok = int((res["status"] == 0).sum())
         print("%-8s %-5s ok %d/%d ratio %.3f  %.1f GiB/s source" % (cname, mname, ok, n, res["comp_size"].sum() / (n * size), n * size / dt / 2**30), flush=True)
