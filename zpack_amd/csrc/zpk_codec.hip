@@ -27,7 +27,7 @@ using namespace zpk;
 // counters layout (u32): [0..3] count per work list, [4..7] dequeue head per list
 enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4, N_LISTS = 3 };
 // [8] dequeue head of k_zstd_fse, [9] Zstandard entries finished on pre-decoded sequences, [10] finished by the fused decoder
-enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, N_COUNTERS = 32 };
+enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT = 17, N_COUNTERS = 32 };
 
 // ------------------------------------------------------------------------------------ kernels
 
@@ -201,15 +201,16 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
                                                                u8* dst, zpk_decode_result* __restrict__ res,
                                                                const u32* __restrict__ list, u32* __restrict__ counters,
                                                                u8* __restrict__ lit_scratch, const u64* __restrict__ arena,
-                                                               u32* __restrict__ zstate)
+                                                               u32* __restrict__ zstate, u32* __restrict__ leftover)
 {
     const int lane = lane_id();
+    const u32 nz = uni(counters[L_ZSTD]);
+    if (nz == 0) return;
     __shared__ __attribute__((aligned(16))) u8 sh_raw[ZSTD_SHARED_EXEC_BYTES];
     ZstdShared& sh = *(ZstdShared*)sh_raw;
     if (threadIdx.x == 0) { sh.defaults_built = 0; sh.huf_valid = 0; }
     __syncthreads();
     u8* lit = lit_scratch + (u64)blockIdx.x * ZSTD_LIT_SCRATCH;
-    const u32 nz = uni(counters[L_ZSTD]);
     for (;;) {
         lane0_guard();
         u32 v = 0;
@@ -218,7 +219,12 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
         lane0_guard();
         if (idx >= nz) break;
         const u32 e = uni(list[idx]);
-        if (uni(zstate[e]) != 1u) continue;
+        if (uni(zstate[e]) != 1u) {                     // not pre-decoded: straight to the full decoder's list
+            lane0_guard();
+            if (lane == 0) leftover[atomicAdd(&counters[C_LEFT_COUNT], 1u)] = e;
+            lane0_guard();
+            continue;
+        }
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
@@ -240,7 +246,10 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
                 res[e] = r;
                 zstate[e] = 2u;
                 atomicAdd(&counters[C_ZSTD_TWO_STAGE], 1u);
-            } else { atomicAdd(&counters[14], 1u); counters[15] = ((u32)(ok ? 0 : 1) << 16) | ((u32)(-o.rc) & 0xFFFFu); }
+            } else {
+                leftover[atomicAdd(&counters[C_LEFT_COUNT], 1u)] = e;
+                atomicAdd(&counters[14], 1u); counters[15] = ((u32)(-o.rc) & 0xFFFFu);
+            }
         }
     }
 }
@@ -249,18 +258,24 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
 __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                           u8* dst, zpk_decode_result* __restrict__ res,
                                                           const u32* __restrict__ list, u32* __restrict__ counters,
-                                                          u8* __restrict__ lit_scratch, u64* __restrict__ dbg,
-                                                          const u32* __restrict__ zstate)
+                                                          u8* __restrict__ lit_scratch, u64* __restrict__ dbg, int count_word)
 {
+    // `list` / counters[count_word]: the Zstandard work list itself, or what k_zstd_exec left over
     const int lane = lane_id();
+    const u32 nz = uni(counters[count_word]);
+    if (nz == 0) return;
     __shared__ ZstdShared sh;
     if (threadIdx.x == 0) { sh.defaults_built = 0; sh.huf_valid = 0; }
     __syncthreads();
     u8* lit = lit_scratch + (u64)blockIdx.x * ZSTD_LIT_SCRATCH;
-    u32 idx;
-    while (dequeue(counters, L_ZSTD, lane, idx)) {
+    for (;;) {
+        lane0_guard();
+        u32 v = 0;
+        if (lane == 0) v = atomicAdd(&counters[L_COUNT + L_ZSTD], 1u);
+        const u32 idx = uni(v);
+        lane0_guard();
+        if (idx >= nz) break;
         const u32 e = uni(list[idx]);
-        if (zstate != nullptr && uni(zstate[e]) == 2u) continue;
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
@@ -435,7 +450,8 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     static const int fused_only = getenv("ZPK_ZSTD_FUSED") ? atoi(getenv("ZPK_ZSTD_FUSED")) : 0;
     bool two_stage = !fused_only && dst_size >= 64;
     if (two_stage && (grow(c, (void**)&c->d_zarena, &c->zarena_cap, dst_size + 64) != ZPK_OK ||
-                      grow(c, (void**)&c->d_zstate, &c->zstate_cap, n * sizeof(u32)) != ZPK_OK)) { two_stage = false; c->err[0] = 0; }
+                      grow(c, (void**)&c->d_zstate, &c->zstate_cap, 2 * n * sizeof(u32)) != ZPK_OK)) { two_stage = false; c->err[0] = 0; }
+    u32* const leftover = two_stage ? c->d_zstate + n : nullptr;          // entries k_zstd_exec hands to the full decoder
     ZPK_KEV(ZPK_K_ZSTD_FSE, 0);
     if (!(skip & 4) && two_stage) {
         HIPCHK(c, hipMemsetAsync(c->d_zstate, 0, n * sizeof(u32), st));          // entries k_zstd_fse never reaches stay unmarked
@@ -448,9 +464,10 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_KEV(ZPK_K_ZSTD, 0);
     if (!(skip & 4) && two_stage)
         hipLaunchKernelGGL(k_zstd_exec, dim3((u32)(n < ZSTD_EXEC_GRID_MAX ? n : ZSTD_EXEC_GRID_MAX)), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
-                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_zarena, c->d_zstate);
+                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_zarena, c->d_zstate, leftover);
     if (!(skip & 4)) hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
-                       c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_dbg, two_stage ? c->d_zstate : (const u32*)nullptr);
+                       two_stage ? (const u32*)leftover : (const u32*)(c->d_lists + L_ZSTD * stride), c->d_counters, c->d_lit, c->d_dbg,
+                       two_stage ? (int)C_LEFT_COUNT : (int)L_ZSTD);
     ZPK_KEV(ZPK_K_ZSTD, 1);
     ZPK_TRACE_STEP("k_zstd");
     if (trace == 2) {

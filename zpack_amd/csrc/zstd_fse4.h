@@ -171,6 +171,7 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                                                  const u32* __restrict__ list, u32* __restrict__ counters,
                                                  u64* __restrict__ arena, u32* __restrict__ state)
 {
+    if (counters[ZF_COUNT_WORD] == 0) return;        // no Zstandard entry in the batch
     __shared__ ZfShared sh;
     const int lane = lane_id();
     const int row = lane >> 4, sub = lane & 15;
