@@ -21,3 +21,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_first(request):
+    """On a GPU box, let torch bring up ITS HIP runtime before the codec library (linked against /opt/rocm) loads: the
+    other order leaves torch without a device in the same process ("No HIP GPUs are available"), whatever the test
+    selection or file order.  Device memory and streams come from torch in the device-resident tests."""
+    if request.config.getoption("-m") and "not gpu" in request.config.getoption("-m"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            torch.zeros(1, device="cuda:0")
+    except Exception:
+        pass
