@@ -44,6 +44,23 @@ for cls, cname in enumerate(["text", "records", "random", "runs"]):
         total_c = int(offs[-1].item())
         res = dres.cpu().numpy().view(zpack_amd.ENCODE_RESULT)
         assert total_c == int(res["comp_size"][res["status"] == 0].sum())
+        # round trip at full size: the packed stream decodes (GPU) to entries whose bytes and XXH3 equal the sources / the
+        # hashes the encoder took of them, every status 0 — encoder + compaction + decoder end to end
+        ddesc2 = np.zeros(n, dtype=zpack_amd.DECODE_DESC)
+        ho = offs.cpu().numpy().view(np.uint64)
+        ddesc2["src_offset"] = ho[:-1]; ddesc2["comp_size"] = res["comp_size"]; ddesc2["uncomp_size"] = size
+        ddesc2["expect_hash"] = res["hash"]; ddesc2["dst_offset"] = np.arange(n, dtype=np.uint64) * size
+        ddesc2["dst_capacity"] = size; ddesc2["method"] = method
+        back = torch.empty(n * size, dtype=torch.uint8, device=dev)
+        dres2 = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        pk = torch.cat([packed[:total_c], torch.zeros(64, dtype=torch.uint8, device=dev)])      # (offset + size < archive size guard)
+        codec.decode_batch_device(pk, torch.from_numpy(ddesc2.view(np.uint8)).to(dev), n, back, dres2)
+        torch.cuda.synchronize()
+        r2 = dres2.cpu().numpy().view(zpack_amd.DECODE_RESULT)
+        rt_ok = bool((r2["status"] == 0).all() and np.array_equal(r2["hash"], res["hash"]) and torch.equal(back, src[: n * size]))
+        del back, pk
+        print("         round trip (encode -> pack -> GPU decode; bytes + XXH3): %s" % ("ok" if rt_ok else "FAILED"), flush=True)
+        assert rt_ok
         print("         pack: %.3f ms wall, k_pack_gather %.3f ms = %.0f GB/s (read + write of %.2f GB packed)" %
               (dtp * 1e3, gather_ms, 2 * total_c / (gather_ms * 1e-3) / 1e9, total_c / 1e9), flush=True)
         ok = int((res["status"] == 0).sum())
