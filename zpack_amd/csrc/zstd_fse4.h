@@ -2,9 +2,9 @@
 //
 // Why.  The sequences section of a block (RFC 8878 3.1.1.3.2) is a serial state machine: ~700 cycles of dependent
 // work per sequence for a wave, and the number of streams a CU can have in flight is bounded by the LDS their
-// three decode tables take (5 KiB).  The fused kernel (zstd_wg.h) spends a whole wave, 168 VGPRs and 13 KiB of LDS
-// on ONE stream (12 per CU) and 77 % of a text entry's time in that chain.  Here a stream costs a quarter of a
-// wave and 6 KiB (tables + a 512-byte bitstream ring + construction scratch): 24 streams per CU, and a wave
+// three decode tables take.  The fused kernel (zstd_wg.h) spends a whole wave, 168 VGPRs and 13 KiB of LDS on ONE
+// stream (12 per CU) and 77 % of a text entry's time in that chain.  Here a stream costs a quarter of a wave and
+// 4.9 KiB (3-byte table cells + a 512-byte bitstream ring + construction scratch): 32 streams per CU, and a wave
 // instruction advances four chains at once.
 //
 // What.  k_zstd_fse walks every frame and block of an entry exactly like zstd_decode_wave, skips the literals
