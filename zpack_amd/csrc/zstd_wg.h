@@ -441,6 +441,7 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
                                           const HufRun& old, u8* out, u64 deadline, bool& bad)
 {
     HufRun r; r.n = 0; r.m0 = 0; r.m1 = 0;
+    u32 wacc = 0;
     i32 pos = entry;
     b.seek(pos);
     bool merged = false;
@@ -456,10 +457,14 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
         u32 nb = (u32)mb;                                    // code length: max_bits + 1 - weight class, the class from the class starts
         #pragma unroll
         for (int w = 0; w < 11; w++) nb -= idx >= rk[w] ? 1u : 0u;
-        if (MODE == 2) st8(out + r.n, huf[idx]);
+        if (MODE == 2) {                                     // four symbols per store: byte stores cost a TA pass and a partial line each
+            wacc |= (u32)huf[idx] << (8u * (r.n & 3u));
+            if ((r.n & 3u) == 3u) { st32(out + (r.n - 3u), wacc); wacc = 0; }
+        }
         pos -= (i32)nb;
         r.n++;
     }
+    if (MODE == 2) for (u32 k = r.n & ~3u; k < r.n; k++) { st8(out + k, (u8)wacc); wacc >>= 8; }
     r.exit = pos;
     if (MODE == 1 && merged) {
         const u32 rel = (u32)(top - pos);
