@@ -914,8 +914,10 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
     }
     const u64 rest = lit_size - lit_pos;
     if (rest > (u64)(oend - op)) { produced = (u64)(op - dst); return D_DST_FULL; }
-    if (lit_rle) { for (u64 i = lane; i < rest; i += WAVE) op[i] = (u8)lit_rle_byte; }
-    else { for (u64 i = lane; i < rest; i += WAVE) op[i] = lit[lit_pos + i]; }
+    if (lit_rle) {
+        u128 pat; pat.lo = 0x0101010101010101ull * (u64)(lit_rle_byte & 0xFFu); pat.hi = pat.lo;
+        for (u64 i = (u64)lane * 16; i < rest; i += WAVE * 16) gstore_upto16(op + i, pat, (u32)(rest - i < 16 ? rest - i : 16));
+    } else for (u64 i = (u64)lane * 16; i < rest; i += WAVE * 16) gcopy_upto16(op + i, lit + lit_pos + i, (u32)(rest - i < 16 ? rest - i : 16));
     op += rest;
     wave_mem_fence();
     if ((u64)(op - dst) > ZSTD_BLOCK_MAX) return D_MALFORMED;
@@ -1010,13 +1012,16 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const
             if (type == 0) {
                 if (bsize > (u64)(iend - ip)) { r.rc = D_MALFORMED; fail = true; break; }
                 if (bsize > (u64)(oend - op)) { r.rc = D_DST_FULL; fail = true; break; }
-                for (u64 i = lane; i < bsize; i += WAVE) op[i] = ip[i];
+                for (u64 i = (u64)lane * 16; i < bsize; i += WAVE * 16) gcopy_upto16(op + i, ip + i, (u32)(bsize - i < 16 ? bsize - i : 16));
                 ip += bsize; op += bsize;
             } else if (type == 1) {
                 if (iend - ip < 1) { r.rc = D_MALFORMED; fail = true; break; }
                 if (bsize > (u64)(oend - op)) { r.rc = D_DST_FULL; fail = true; break; }
                 const u8 v = (u8)uld8(ip);
-                for (u64 i = lane; i < bsize; i += WAVE) op[i] = v;
+                {
+                    u128 pat; pat.lo = 0x0101010101010101ull * v; pat.hi = pat.lo;
+                    for (u64 i = (u64)lane * 16; i < bsize; i += WAVE * 16) gstore_upto16(op + i, pat, (u32)(bsize - i < 16 ? bsize - i : 16));
+                }
                 ip += 1; op += bsize;
             } else {
                 if (bsize > (u64)(iend - ip) || bsize >= ZSTD_BLOCK_MAX) { r.rc = D_MALFORMED; fail = true; break; }
