@@ -320,7 +320,10 @@ __device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
         u32 w = sh.weights[i];
         if (!w) continue;
         u32 len = 1u << (w - 1), base = sh.sym_start[i];
-        for (u32 k = lane; k < len; k += WAVE) sh.huf[base + k] = (u8)i;
+        // max_bits <= 11 (what libzstd emits for literals): 2^11 u16 entries, symbol | code length << 8, fit the same 4 KiB, and
+        // the decoder gets the length with the symbol; a 12-bit code keeps the byte table + the rank thresholds
+        if (sh.huf_max_bits <= 11) { const u16 ent = (u16)(i | ((sh.huf_max_bits + 1 - w) << 8)); for (u32 k = lane; k < len; k += WAVE) ((u16*)sh.huf)[base + k] = ent; }
+        else for (u32 k = lane; k < len; k += WAVE) sh.huf[base + k] = (u8)i;
     }
     __syncthreads();
     sh.huf_valid = 1;
@@ -436,7 +439,7 @@ struct HufBits {
 // MODE 1: the same, but stop as soon as the position is one the previous pass visited — from there on the two
 //         passes are identical, so the previous count and exit are inherited; MODE 2: decode and store.
 struct HufRun { i32 exit; u32 n; u64 m0, m1; };
-template <int MODE>
+template <int MODE, bool WIDE>
 __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, const u32 (&rk)[11], int mb, i32 entry, i32 lo, i32 top,
                                           const HufRun& old, u8* out, u64 deadline, bool& bad)
 {
@@ -454,11 +457,16 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
         }
         if ((r.n & 4095u) == 4095u && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
         const u32 idx = b.peek(pos - mb, mb);              // zeros below bit 0
-        u32 nb = (u32)mb;                                    // code length: max_bits + 1 - weight class, the class from the class starts
-        #pragma unroll
-        for (int w = 0; w < 11; w++) nb -= idx >= rk[w] ? 1u : 0u;
+        u32 nb, sym;
+        if (WIDE) { const u32 ent = ((const ZPK_LDS u16*)huf)[idx]; nb = ent >> 8; sym = ent & 0xFFu; }
+        else {
+            nb = (u32)mb;                                    // code length: max_bits + 1 - weight class, the class from the class starts
+            #pragma unroll
+            for (int w = 0; w < 11; w++) nb -= idx >= rk[w] ? 1u : 0u;
+            sym = MODE == 2 ? (u32)huf[idx] : 0u;
+        }
         if (MODE == 2) {                                     // four symbols per store: byte stores cost a TA pass and a partial line each
-            wacc |= (u32)huf[idx] << (8u * (r.n & 3u));
+            wacc |= sym << (8u * (r.n & 3u));
             if ((r.n & 3u) == 3u) { st32(out + (r.n - 3u), wacc); wacc = 0; }
         }
         pos -= (i32)nb;
@@ -521,13 +529,19 @@ __device__ __noinline__ bool huf_decode_streams(const ZPK_LDS u8* huf, const ZPK
     HufBits b; b.start = sp; b.rd_hi = rd_hi;
     HufRun r; r.exit = top; r.n = 0; r.m0 = r.m1 = 0;
     i32 entry = top;
-    if (act) r = huf_run<0>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad);
+    const bool wide = mb <= 11;                                        // uniform: the table holds symbol | length (huf_build)
+    if (act) r = wide ? huf_run<0, true>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad)
+                      : huf_run<0, false>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad);
     for (int iter = 0; iter < 17; iter++) {
         i32 e = __shfl_up(r.exit, 1, 16);
         if (j == 0) e = P;
         const bool changed = act && e != entry;
         if (__ballot(changed) == 0) break;
-        if (changed) { entry = e; r = huf_run<1>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad); }
+        if (changed) {
+            entry = e;
+            r = wide ? huf_run<1, true>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad)
+                     : huf_run<1, false>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad);
+        }
     }
     // place the pieces: prefix sum of the symbol counts inside each 16-lane row
     u32 x = act ? r.n : 0u;
@@ -539,7 +553,10 @@ __device__ __noinline__ bool huf_decode_streams(const ZPK_LDS u8* huf, const ZPK
     const i32 last_exit = __shfl(r.exit, lane | 15, 64);
     if (act && ((u64)total != cnt || last_exit != 0)) bad = true;      // libzstd: exact symbol count and BIT_endOfDStream
     if (__ballot(bad) != 0) return false;
-    if (act) (void)huf_run<2>(b, huf, rk, mb, entry, lo, top, r, out + (x - r.n), deadline, bad);
+    if (act) {
+        if (wide) (void)huf_run<2, true>(b, huf, rk, mb, entry, lo, top, r, out + (x - r.n), deadline, bad);
+        else (void)huf_run<2, false>(b, huf, rk, mb, entry, lo, top, r, out + (x - r.n), deadline, bad);
+    }
     return __ballot(bad) == 0;
 }
 
