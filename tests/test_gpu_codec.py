@@ -305,3 +305,16 @@ def test_corrupted_frames_same_verdict_and_bytes_as_oracle(codec, method, level)
     assert st["fse_watchdog"] == 0 and st["fse_budget"] == 0
     if method == dg.ZSTD:
         assert st["zstd_two_stage"] + st["zstd_fused"] == n
+
+
+def test_huffman_12_bit_code_frame(codec):
+    """12-bit Huffman literals (tests/huf12.py): the table layout the GPU keeps for codes longer than 11 bits."""
+    from tests.huf12 import make_frame
+    o = oracle()
+    for seed, n in ((1, 200), (2, 1000), (3, 17)):
+        frame, lits = make_frame(seed, n)
+        e = dict(offset=10, comp_size=len(frame), uncomp_size=n, hash=o.xxh3(lits), method=1)
+        arc = zpk.assemble([frame], [("f", 10, len(frame), n, e["hash"], 1)])
+        res, outs = codec.decode_batch_host(arc, _desc([e], [n]))
+        assert int(res[0]["status"]) == 0 and int(res[0]["produced"]) == n, res[0]
+        assert outs[0][:n].tobytes() == lits

@@ -155,3 +155,24 @@ def test_oracle_encoders_decode_with_real_libraries():
             assert r == 0 and dn.value == n and sn.value == len(f) and out.raw[:n] == plain, (cls, n, r)
             if cls != dg.RANDOM and n >= 4096:
                 assert len(f) < n
+
+
+def test_huffman_12_bit_code_frame():
+    """The hand-built frame of tests/huf12.py (12-bit Huffman literals): the oracle decodes it, and so does the real
+    libzstd of the image when it is there."""
+    import ctypes as C
+    from tests.huf12 import make_frame
+    o = oracle()
+    for seed, n in ((1, 200), (2, 1000), (3, 17)):
+        frame, lits = make_frame(seed, n)
+        rc, out = o.zstd_decode(frame, n)
+        assert rc == 0 and out == lits
+        for so in ("/opt/conda/lib/libzstd.so.1", "libzstd.so.1"):
+            try:
+                z = C.CDLL(so)
+            except OSError:
+                continue
+            z.ZSTD_decompress.restype = C.c_size_t
+            buf = (C.c_uint8 * n)()
+            assert z.ZSTD_decompress(buf, n, frame, len(frame)) == n and bytes(buf) == lits
+            break
