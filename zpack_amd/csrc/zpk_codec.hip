@@ -201,7 +201,7 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
                                                                u8* dst, zpk_decode_result* __restrict__ res,
                                                                const u32* __restrict__ list, u32* __restrict__ counters,
                                                                u8* __restrict__ lit_scratch, const u64* __restrict__ arena,
-                                                               u32* __restrict__ zstate, u32* __restrict__ leftover)
+                                                               u32* __restrict__ zstate, u32* __restrict__ leftover, u64* __restrict__ dbg)
 {
     const int lane = lane_id();
     const u32 nz = uni(counters[L_ZSTD]);
@@ -230,7 +230,18 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
         u8* out = uni_ptr(dst + d.dst_offset);
         const u64* const pre = arena + (((u64)d.dst_offset + 7) >> 3);
         Watchdog wd; wd.arm();
+#ifdef ZPK_STATS
+        ZstdStats zs = {};
+        const u64 t_all = SEQ_T();
+        DecodeOut o = zstd_decode_wave<true>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, &zs, pre);
+        if (dbg && lane == 0) {
+            u64* g = dbg + (u64)e * 8;
+            g[0] = zs.t_lit; g[1] = zs.t_tab; g[2] = zs.t_fse; g[3] = zs.t_exec; g[4] = zs.nseq; g[5] = zs.nblk; g[6] = SEQ_T() - t_all; g[7] = 1;
+        }
+#else
+        (void)dbg;
         DecodeOut o = zstd_decode_wave<true>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, nullptr, pre);
+#endif
         bool ok = o.rc == D_OK;
         u64 h = 0;
         lane0_guard();
@@ -464,7 +475,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_KEV(ZPK_K_ZSTD, 0);
     if (!(skip & 4) && two_stage)
         hipLaunchKernelGGL(k_zstd_exec, dim3((u32)(n < ZSTD_EXEC_GRID_MAX ? n : ZSTD_EXEC_GRID_MAX)), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
-                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_zarena, c->d_zstate, leftover);
+                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_zarena, c->d_zstate, leftover, c->d_dbg);
     if (!(skip & 4)) hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
                        two_stage ? (const u32*)leftover : (const u32*)(c->d_lists + L_ZSTD * stride), c->d_counters, c->d_lit, c->d_dbg,
                        two_stage ? (int)C_LEFT_COUNT : (int)L_ZSTD);
