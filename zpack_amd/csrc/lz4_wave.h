@@ -99,7 +99,8 @@ struct Lz4Bytes {
     }
 };
 
-// flags: 1 = malformed, 2 = this was the block's last (literal-only) sequence
+// flags: 1 = malformed (| 4: found AFTER the literal run, i.e. the reference copies the literals first), 2 = this was the
+// block's last (literal-only) sequence
 struct Lz4Tok { u32 next, lit_pos, lit, ml, off, flags; };
 
 // full decode of the sequence whose token is at block position p (p < C)
@@ -120,17 +121,17 @@ __device__ __forceinline__ Lz4Tok lz4_token_at(const Lz4Bytes& B, u32 p, u32 C, 
     if (lit > C - q) { t.flags = 1; t.next = C; return t; }
     q += lit;
     if (q == C) { t.flags = 2; t.next = C; return t; }
-    if (C - q < 2) { t.flags = 1; t.next = C; return t; }
+    if (C - q < 2) { t.flags = 5; t.next = C; return t; }
     if (want_offset) t.off = B.at16(q);
     q += 2;
     u32 ml = tok & 15;
     if (ml == 15) {
         u32 b;
         do {
-            if (q >= C) { t.flags = 1; t.next = C; return t; }
+            if (q >= C) { t.flags = 5; t.next = C; return t; }
             b = B.at(q++); ml += b;
         } while (b == 255 && ml < 0x7F000000u);
-        if (b == 255) { t.flags = 1; t.next = C; return t; }
+        if (b == 255) { t.flags = 5; t.next = C; return t; }
     }
     t.ml = ml + 4;
     t.next = q;
@@ -304,7 +305,8 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         const int last_lane = 63 - __clzll((long long)lastmask);
         const u32 chain_exit = (u32)__builtin_amdgcn_readlane((int)w.exit, last_lane);
         const u32 fl = (u32)__ballot(active && (w.flags & 1)) != 0 || (__ballot(active && (w.flags & 1)) >> 32) != 0 ? 1u : 0u;
-        if (fl) return D_MALFORMED;
+        // (a malformed token ends the chain; it is the chunk's last listed sequence, and the executor below gives the
+        // verdict of whichever sequence offends FIRST, in stream order, like the reference's serial decoder)
         if (__ballot(active && (w.flags & 2)) != 0) finished = true;          // the block's last sequence is in this chunk
         // ---- sequence numbers + token records ----
         const u32 my_nseq = active ? (u32)__popcll(w.m) : 0u;
@@ -332,8 +334,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             }
             const int cnt = (int)(nseq - b0 < WAVE ? nseq - b0 : WAVE);
             const u64 tq0 = SEQ_T(); (void)tq0;
-            SeqBatch q; q.lit = ip; q.lit_lds = SEQ_NO_LDS; q.ll = 0; q.ml = 0; q.off = 1;
-            bool bad = false;
+            SeqBatch q; q.lit = ip; q.lit_lds = SEQ_NO_LDS; q.ll = 0; q.ml = 0; q.off = 1; q.bad = 0;
             const u32 sq = b0 + (u32)lane;
             u32 tok_pos = cpos;
             if (lane < cnt) {
@@ -347,24 +348,21 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
                 Lz4Tok t;
                 if (interior && lit != 15 && !(mlc == 15 && eb == 255)) {            // straight-line common case
                     q.lit = ip + p + 1; q.ll = lit; q.ml = mlc + 4 + (mlc == 15 ? eb : 0u); q.off = o16;
-                    bad = o16 == 0;
                 } else if (lz4_token_fast<true>(B, p, C, tok, t)) {                         // common case: 2-4 LDS reads in all
                     q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
-                    bad = q.off == 0 || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
                 } else {
                     t = lz4_token_at(B, p, C, true);
                     q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
-                    bad = (t.flags & 1) || (t.ml && t.off == 0) || t.lit > (u64)(oend - op) || t.ml > (u64)(oend - op);
+                    if (t.flags & 1) q.bad = (t.flags & 4) ? 2u : 1u;
                 }
+                // (a block holds at most 4 MiB of output: longer lengths only have to stay longer than that, and 64 of them
+                // must not wrap the 32-bit prefix sums)
+                if (q.ll > (1u << 23)) q.ll = 1u << 23;
+                if (q.ml > (1u << 23)) q.ml = 1u << 23;
                 const u32 lp = (u32)(q.lit - ip);                                      // literals that sit in the staged chunk
                 if (q.ll <= SEQ_OWN_MAX && lp + q.ll <= B.cend) q.lit_lds = lp - B.cbase;
             }
             SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_parse += t2 - tq0; stt.t_tok += t2 - tq0; });
-            if (__ballot(bad) != 0) {
-                // oversize lengths mean the output slot is too small (or the input is malformed): let the sums decide
-                if (__ballot(lane < cnt && (q.ll > (u64)(oend - op) || q.ml > (u64)(oend - op))) != 0) { op_io = op; return D_DST_FULL; }
-                return D_MALFORMED;
-            }
             // Input this chunk has already consumed (everything before the batch's first token) is dead: the
             // executor assembles the batch there.  The first batch or two of a chunk find too little room and
             // take the direct path.
@@ -372,6 +370,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             const int rc = seq_exec_batch(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
             if (rc != D_OK) { op_io = op; return rc; }
         }
+        if (fl) return D_MALFORMED;                                            // (not reached: the executor saw the malformed token)
         if (!finished && chain_exit <= cpos) return D_MALFORMED;               // no progress: cannot happen
         cpos = chain_exit;
     }

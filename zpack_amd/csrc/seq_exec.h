@@ -182,6 +182,7 @@ struct SeqBatch {
     u32 lit_lds;       // byte offset of the same literals in the caller's LDS staging buffer, or SEQ_NO_LDS
     u32 ll, ml;        // literal length, match length (0 = no match)
     u32 off;           // match offset (>= 1 when ml != 0)
+    u32 bad;           // 0; 1 = the sequence is malformed before its literal run, 2 = after it (the reference copies the literals first)
 };
 
 // In-batch dependency analysis: pure cross-lane arithmetic (ds_bpermute + ALU, no memory).
@@ -269,11 +270,24 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     // ---- 1. output positions ----
     const u32 x = wave_scan_add(ll + ml);
     const u64 total = (u32)__builtin_amdgcn_readlane((int)x, 63);
-    if (total > (u64)(oend - op)) return D_DST_FULL;
     u8* const o = op + (x - (ll + ml));          // literal start of this lane's sequence
     u8* const ms = o + ll;                        // match start
     const bool has_match = act && ml != 0;
-    if (__ballot(has_match && (q.off == 0 || (u64)q.off > (u64)(ms - dst_lo))) != 0) return D_MALFORMED;
+    {   // The verdict is that of the FIRST offending sequence in stream order, with the checks of one sequence in the order
+        // of a serial decoder (malformed token / literals do not fit / bad offset or truncated match / match does not fit):
+        // a batch is 64 sequences examined at once, but `output too small` and `malformed` are different results upstream.
+        const u64 cap = (u64)(oend - op);
+        const bool off_bad = has_match && (q.off == 0 || (u64)q.off > (u64)(ms - dst_lo));
+        u32 v = 0;                                // 1 malformed, 2 does not fit
+        if (act) {
+            if (q.bad == 1) v = 1;
+            else if ((u64)(x - ml) > cap) v = 2;
+            else if (q.bad == 2 || off_bad) v = 1;
+            else if ((u64)x > cap) v = 2;
+        }
+        const u64 vm = __ballot(v != 0);
+        if (vm != 0) return (u32)__builtin_amdgcn_readlane((int)v, __ffsll((long long)vm) - 1) == 1u ? D_MALFORMED : D_DST_FULL;
+    }
     u64 pending = __ballot(has_match);
 
     // ---- 2. in-batch dependencies (positions relative to op) ----

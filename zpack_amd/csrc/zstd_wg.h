@@ -663,7 +663,7 @@ __device__ __noinline__ int zstd_sequences_pre(ZPK_LDS ZstdShared* sh, ZSeqArgs*
         SeqBatch q;
         const u64 my_lit = lit_pos + (xl - (lane < cnt ? my_ll : 0u));
         q.lit = lit + my_lit;
-        q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = my_off;
+        q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = my_off; q.bad = 0;
         if (!lit_rle && lit_total != 0) {
             if (lit_total <= ZSEQ_LWIN && (lit_pos < win_lo || lit_pos + lit_total > win_lo + ZSEQ_LWIN)) {
                 wave_mem_fence();
@@ -797,7 +797,7 @@ __device__ __noinline__ int zstd_sequences(ZPK_LDS ZstdShared* sh, ZSeqArgs* a, 
                 if (__ballot(lane < cnt && (my_off == 0 || my_off > 0xFFFFFFFFull)) != 0) return D_MALFORMED;
                 SeqBatch q;
                 q.lit = lit + lit_pos + (xl - (lane < cnt ? my_ll : 0u));
-                q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = (u32)my_off;
+                q.lit_lds = SEQ_NO_LDS; q.ll = my_ll; q.ml = my_ml; q.off = (u32)my_off; q.bad = 0;
                 SeqStats stt = {};
                 (void)stt;
                 const int rc = seq_exec_batch(q, cnt, op, oend, frame_lo, lit_rle ? (int)lit_rle_byte : -1, lane, stt);
