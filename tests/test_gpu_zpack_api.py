@@ -211,3 +211,45 @@ def test_batch_write_then_batch_read_roundtrip(Z, method, level):
     assert Z.lib.zpack_read_files(C.byref(r), ptrs, n, bufs, caps, results, None) == 0
     assert results[5] == 15 and all(results[i] == 0 for i in range(n) if i != 5 and len(want[i][1]))
     Z.close_reader(r)
+
+
+@pytest.mark.parametrize("method,level", [(METHOD_ZSTD, 1), (METHOD_LZ4, 0)])
+def test_encoder_stress_alphabets_and_boundaries(Z, method, level):
+    """Inputs aimed at the device encoders' corner cases — literal-heavy data over alphabets of 2..129 symbols with
+    geometric / Fibonacci-like frequencies (Huffman depth beyond 11 bits -> the length limiter, 1-bit codes, the
+    128-weight limit of the direct tree description -> Raw fallback), short periods, constant data, and sizes around the
+    64 KiB block and the 2 KiB Huffman threshold.  Every archive must decode bit-exactly with the oracle and with stock
+    libzstd / liblz4 (compiled reference)."""
+    rng = np.random.default_rng(12345)
+    want = []
+
+    def add(name, arr):
+        want.append(("%s_%03d" % (name, len(want)), np.asarray(arr, dtype=np.uint8).tobytes()))
+
+    for nsym in (2, 3, 17, 64, 127, 128, 129, 200):
+        base = 0 if nsym <= 128 else 40
+        for kind in ("geom", "fib", "flat"):
+            if kind == "geom":
+                p = 0.5 ** np.arange(1, nsym + 1, dtype=np.float64); p[-1] += 1 - p.sum()
+            elif kind == "fib":
+                f = [1.0, 1.0]
+                while len(f) < nsym:
+                    f.append(f[-1] + f[-2] if f[-1] < 1e12 else f[-1])
+                p = np.array(f[:nsym][::-1]); p /= p.sum()
+            else:
+                p = np.full(nsym, 1.0 / nsym)
+            p = np.maximum(p, 1e-9); p /= p.sum()
+            add("%s%d" % (kind, nsym), base + rng.choice(nsym, size=70000, p=p))
+    for n in (2047, 2048, 2049, 4096, 65535, 65536, 65537, 131071, 131072, 131073):
+        add("sz", 97 + rng.choice(26, size=n, p=np.array([2.0 ** -(i // 3 + 1) for i in range(26)]) / sum(2.0 ** -(i // 3 + 1) for i in range(26))))
+    add("const", np.full(100000, 7))
+    add("period3", np.tile([1, 2, 3], 40000))
+    add("period257", np.tile(np.arange(257) % 251, 300))
+    add("zeros_then_text", np.concatenate([np.zeros(70000, dtype=np.uint8), dg.fill(dg.TEXT, 3, 0, 70000)]))
+    arc = Z.write_archive(want, method, level)
+    _decode_all_with_checkers(arc, want)
+    ents = {e["filename"]: e for e in zpk.parse(arc)}          # skewed data must shrink, flat 200-symbol data must not blow up
+    for name, data in want:
+        if name.startswith("geom") or name.startswith("const") or name.startswith("period"):
+            assert ents[name]["comp_size"] < 0.8 * len(data), (name, ents[name]["comp_size"])
+        assert ents[name]["comp_size"] <= len(data) + len(data) // 200 + 64, (name, ents[name]["comp_size"])
