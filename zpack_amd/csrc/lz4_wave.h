@@ -357,7 +357,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
                 }
                 // (a block holds at most 4 MiB of output: longer lengths only have to stay longer than that, and 64 of them
                 // must not wrap the 32-bit prefix sums)
-                if (q.ll > (1u << 23)) q.ll = 1u << 23;
+                if (q.ll > (1u << 23)) q.ll = 1u << 23;            // 64 x 2 x 2^23 = 2^30: the executor's 32-bit arithmetic holds
                 if (q.ml > (1u << 23)) q.ml = 1u << 23;
                 const u32 lp = (u32)(q.lit - ip);                                      // literals that sit in the staged chunk
                 if (q.ll <= SEQ_OWN_MAX && lp + q.ll <= B.cend) q.lit_lds = lp - B.cbase;
@@ -367,7 +367,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             // executor assembles the batch there.  The first batch or two of a chunk find too little room and
             // take the direct path.
             const u32 dead = (u32)__builtin_amdgcn_readfirstlane((int)tok_pos) - cpos;
-            const int rc = seq_exec_batch(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
+            const int rc = seq_exec_batch<true>(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
             if (rc != D_OK) { op_io = op; return rc; }
         }
         if (fl) return D_MALFORMED;                                            // (not reached: the executor saw the malformed token)

@@ -260,6 +260,9 @@ __device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_
 // read back from there at LDS latency instead of a store->load round trip through L2, and the finished batch
 // goes to memory as one contiguous 16-bytes-per-lane stream — one or two full store instructions instead of
 // ~17 partially filled ones.
+// NARROW_ONLY: the caller guarantees 31-bit positions and offsets (LZ4: 16-bit offsets, lengths clamped to 2^23), so only
+// the 32-bit dependency analysis is instantiated.
+template <bool NARROW_ONLY = false>
 __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& op, u8* oend, const u8* dst_lo, int lit_rle, int lane,
                                               SeqStats& stt, lds_cp8 lit_stage = nullptr, lds_p8 asm_buf = nullptr, u32 asm_cap = 0)
 {
@@ -294,9 +297,13 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     const u32 r_ms = (u32)(ms - op), r_me = r_ms + ml;           // this lane's match output [r_ms, r_me)
     const u32 need_len = ml < q.off ? ml : q.off;                 // bytes not produced by the match itself
     i64 src;
-    const bool narrow = total < (1u << 30) && __ballot(has_match && q.off >= (1u << 30)) == 0;     // uniform
-    const u64 need = narrow ? seq_dependencies<i32>(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt)
-                            : seq_dependencies<i64>(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt);
+    u64 need;
+    if (NARROW_ONLY) need = seq_dependencies<i32>(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt);
+    else {
+        const bool narrow = total < (1u << 30) && __ballot(has_match && q.off >= (1u << 30)) == 0;     // uniform
+        need = narrow ? seq_dependencies<i32>(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt)
+                      : seq_dependencies<i64>(has_match, r_ms, r_me, q.off, need_len, pending, lane, src, stt);
+    }
     const u8* const srcp = op + src;                               // (possibly re-pointed) source of the first need_len bytes
     const bool self_overlap = ml > need_len;                       // offset < length: the match feeds itself
     const bool coop = has_match && (ml > SEQ_OWN_MAX || self_overlap);
