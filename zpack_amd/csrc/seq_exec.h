@@ -414,33 +414,6 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
         }
         u64 cm = __ballot(ready && coop);
         SEQ_STAT(stt.coops += (u32)__popcll(cm));
-        // Long matches that do not feed themselves (33+ bytes, source complete): ALL of them in one go — their 16-byte
-        // chunks are numbered by a prefix sum, lane j takes chunk j (binary search over the sums for its owner), one load
-        // and one store per 64 chunks.  One match at a time cost a global round trip EACH (structured data: most matches).
-        {
-            const bool g_me = ready && coop && !self_overlap;
-            const u64 gm = __ballot(g_me);
-            if (gm != 0) {
-                const u32 nch = g_me ? (ml + 15u) >> 4 : 0u;
-                const u32 xs = wave_scan_add(nch);
-                const u32 T = (u32)__builtin_amdgcn_readlane((int)xs, 63);
-                const u32 ms_lo = (u32)(u64)ms, ms_hi = (u32)((u64)ms >> 32), sp_lo = (u32)(u64)srcp, sp_hi = (u32)((u64)srcp >> 32);
-                for (u32 base = 0; base < T; base += WAVE) {
-                    const u32 g = base + (u32)lane;
-                    int k = 0;                                   // first lane whose inclusive sum exceeds g
-                    #pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) { const u32 a = (u32)__shfl((int)xs, k + step - 1, 64); if (a <= g) k += step; }
-                    const u32 kx = (u32)__shfl((int)xs, k, 64), kn = (u32)__shfl((int)nch, k, 64), kml = (u32)__shfl((int)ml, k, 64);
-                    const u64 kd = ((u64)(u32)__shfl((int)ms_hi, k, 64) << 32) | (u32)__shfl((int)ms_lo, k, 64);
-                    const u64 ks = ((u64)(u32)__shfl((int)sp_hi, k, 64) << 32) | (u32)__shfl((int)sp_lo, k, 64);
-                    if (g < T) {
-                        const u32 c = (g - (kx - kn)) * 16u;
-                        gcopy_upto16((u8*)kd + c, (const u8*)ks + c, kml - c);
-                    }
-                }
-                cm &= ~gm;
-            }
-        }
         while (cm) {
             const int k = __ffsll((long long)cm) - 1;
             cm &= cm - 1;
@@ -458,15 +431,6 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
                     for (u32 c = (u32)lane * 16; c < slab; c += WAVE * 16) gcopy_upto16(p + base + c, p + base - koff + c, slab - c);
                     wave_mem_fence();
                 }
-            } else if ((koff & (koff - 1)) == 0 && koff <= 8) {
-                // period 1, 2, 4 or 8 (byte runs, 16- / 32- / 64-bit fills): the 16-byte pattern is the same at every
-                // 16-byte chunk, so the whole match is stores of one replicated register
-                u64 v = koff == 8 ? ld64(m) : (koff == 4 ? (u64)ld32(m) : (koff == 2 ? (u64)ld16(m) : (u64)ld8(m)));
-                if (koff == 2) { v &= 0xFFFFull; v |= v << 16; v |= v << 32; }
-                if (koff == 1) { v &= 0xFFull; v *= 0x0101010101010101ull; }
-                if (koff == 4) { v &= 0xFFFFFFFFull; v |= v << 32; }
-                u128 pat; pat.lo = v; pat.hi = v;
-                for (u32 c = (u32)lane * 16; c < n; c += WAVE * 16) gstore_upto16(p + c, pat, n - c);
             } else {
                 for (u32 c = lane; c < n; c += WAVE) st8(p + c, ld8(m + c % koff));
             }
