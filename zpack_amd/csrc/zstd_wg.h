@@ -408,7 +408,8 @@ __device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* s
 struct HufBits {
     const u8* start; const u8* rd_hi;
     i32 cb;               // container covers stream bits [cb*8, cb*8 + 128)
-    u64 c_lo, c_hi, pre;  // pre = the 8 bytes below c_lo, loaded one step ahead
+    u64 c_lo, c_hi, pre, pre2;  // pre / pre2 = the 8 + 8 bytes below c_lo, loaded two steps ahead: with 8-bit codes a step is
+                                // only 8 symbols, less than a memory round trip under load
 
     __device__ __forceinline__ u64 fetch(i32 byte) const
     {
@@ -422,12 +423,12 @@ struct HufBits {
     __device__ __forceinline__ void seek(i32 pos)             // the next reads lie just below bit `pos`
     {
         cb = ((pos + 7) >> 3) - 16;
-        c_lo = fetch(cb); c_hi = fetch(cb + 8); pre = fetch(cb - 8);
+        c_lo = fetch(cb); c_hi = fetch(cb + 8); pre = fetch(cb - 8); pre2 = fetch(cb - 16);
     }
     // bits [bp, bp+n), n <= 12; bp may be negative (zeros below 0)
     __device__ __forceinline__ u32 peek(i32 bp, int n)
     {
-        while (bp < cb * 8) { c_hi = c_lo; c_lo = pre; cb -= 8; pre = fetch(cb - 8); }
+        while (bp < cb * 8) { c_hi = c_lo; c_lo = pre; pre = pre2; cb -= 8; pre2 = fetch(cb - 16); }
         const int rel = bp - cb * 8;
         const u64 v = rel >= 64 ? c_hi >> (rel - 64) : (c_lo >> rel) | ((c_hi << 1) << (63 - rel));
         return (u32)v & ((1u << n) - 1u);
@@ -435,25 +436,51 @@ struct HufBits {
 };
 
 // One pass of one lane over its piece of a stream: decode from bit `entry` while the position is above `lo`.
-// MODE 0: count symbols, remember the positions visited in the first 128 bits below `top` (bit masks);
-// MODE 1: the same, but stop as soon as the position is one the previous pass visited — from there on the two
-//         passes are identical, so the previous count and exit are inherited; MODE 2: decode and store.
-struct HufRun { i32 exit; u32 n; u64 m0, m1; };
+// MODE 0: count symbols, remember the positions visited in the first 128 bits below `top` (bit masks) and six
+//         CHECKPOINTS further down (the position before the 32nd, 64th, ... 1024th symbol, with the number of symbols
+//         from there to the end of the piece);
+// MODE 1: the same, but stop as soon as the position is one the previous pass visited — a mask bit or a checkpoint:
+//         from there on the two passes are identical, so the previous count and exit are inherited.  The checkpoints
+//         matter for codes that re-synchronise slowly (almost fixed-length codes of near-random literals): without them
+//         a re-walk that merges after the mask window decodes the whole piece again, round after round;
+// MODE 2: decode and store.
+#define HUF_NCP 6
+#define HUF_CP_NONE ((i32)0x80000000)
+struct HufRun { i32 exit; u32 n; u64 m0, m1; i32 cp[HUF_NCP]; u32 cr[HUF_NCP]; };
 template <int MODE, bool WIDE>
 __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, const u32 (&rk)[11], int mb, i32 entry, i32 lo, i32 top,
                                           const HufRun& old, u8* out, u64 deadline, bool& bad)
 {
     HufRun r; r.n = 0; r.m0 = 0; r.m1 = 0;
+    #pragma unroll
+    for (int k = 0; k < HUF_NCP; k++) { r.cp[k] = HUF_CP_NONE; r.cr[k] = 0; }
     u32 wacc = 0;
     i32 pos = entry;
     b.seek(pos);
-    bool merged = false;
+    bool merged = false, by_cp = false;
+    // the highest checkpoint of the previous pass at or below the current position (positions only go down)
+    i32 nxt = HUF_CP_NONE;
+    if (MODE == 1) {
+        #pragma unroll
+        for (int k = 0; k < HUF_NCP; k++) if (old.cp[k] <= pos && old.cp[k] > nxt) nxt = old.cp[k];
+    }
     while (pos > lo) {
         const u32 rel = (u32)(top - pos);
         if (MODE != 2 && rel < 128) {
             const u64 bit = 1ull << (rel & 63);
             if (MODE == 1 && ((rel < 64 ? old.m0 : old.m1) & bit)) { merged = true; break; }
             if (rel < 64) r.m0 |= bit; else r.m1 |= bit;
+        }
+        if (MODE == 1 && pos <= nxt) {
+            if (pos == nxt) { merged = true; by_cp = true; break; }
+            nxt = HUF_CP_NONE;                                // passed it: the next one further down
+            #pragma unroll
+            for (int k = 0; k < HUF_NCP; k++) if (old.cp[k] <= pos && old.cp[k] > nxt) nxt = old.cp[k];
+            if (pos == nxt) { merged = true; by_cp = true; break; }
+        }
+        if (MODE != 2 && r.n >= 32u && (r.n & (r.n - 1u)) == 0u && r.n <= (32u << (HUF_NCP - 1))) {
+            #pragma unroll
+            for (int k = 0; k < HUF_NCP; k++) if (r.n == (32u << k)) { r.cp[k] = pos; r.cr[k] = r.n; }       // cr: index for now
         }
         if ((r.n & 4095u) == 4095u && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
         const u32 idx = b.peek(pos - mb, mb);              // zeros below bit 0
@@ -477,10 +504,25 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
     if (MODE == 1 && merged) {
         const u32 rel = (u32)(top - pos);
         const u64 below0 = rel < 64 ? old.m0 & ((1ull << rel) - 1) : old.m0;
-        const u64 below1 = rel < 64 ? 0ull : old.m1 & ((1ull << (rel - 64)) - 1);
-        r.n += old.n - (u32)(__popcll(below0) + __popcll(below1));
+        const u64 below1 = rel < 64 ? 0ull : (rel < 128 ? old.m1 & ((1ull << (rel - 64)) - 1) : old.m1);
+        u32 rest = old.n - (u32)(__popcll(below0) + __popcll(below1));        // mask merge: every earlier symbol of the old pass is in the masks
+        if (by_cp) {
+            #pragma unroll
+            for (int k = 0; k < HUF_NCP; k++) if (old.cp[k] == pos) rest = old.cr[k];
+        }
+        // this pass's own checkpoints lie above the merge point and keep (index -> count to the end) after the sum below;
+        // the old pass's checkpoints at or below it stay valid as they are, those above it belonged to the abandoned prefix
+        #pragma unroll
+        for (int k = 0; k < HUF_NCP; k++) {
+            if (r.cp[k] != HUF_CP_NONE) r.cr[k] = r.n + rest - r.cr[k];
+            else if (old.cp[k] != HUF_CP_NONE && old.cp[k] <= pos) { r.cp[k] = old.cp[k]; r.cr[k] = old.cr[k]; }
+        }
+        r.n += rest;
         r.m0 |= old.m0 & ~below0; r.m1 |= old.m1 & ~below1;
         r.exit = old.exit;
+    } else if (MODE != 2) {
+        #pragma unroll
+        for (int k = 0; k < HUF_NCP; k++) if (r.cp[k] != HUF_CP_NONE) r.cr[k] = r.n - r.cr[k];
     }
     return r;
 }
@@ -492,7 +534,7 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
 // exits converge to the true chain after a few cheap rounds (lane 0 of a stream is right from the start, so
 // the fixed point is the true decode).  A row prefix sum of the counts then places every piece, and one more
 // pass stores the symbols.  Two full passes with 64 lanes instead of one with 4.
-struct HufArgs { const u8* p; u64 size; int nstreams; u8* lit; u64 regen; const u8* rd_hi; u64 deadline; };
+struct HufArgs { const u8* p; u64 size; int nstreams; u8* lit; u64 regen; const u8* rd_hi; u64 deadline; u64* dbg; };
 __device__ __noinline__ bool huf_decode_streams(const ZPK_LDS u8* huf, const ZPK_LDS u32* rank, int mb, const HufArgs* a, int lane)
 {
     const u8* const p = uni_ptr(a->p); const u64 size = uni64(a->size); const int nstreams = (int)uni((u32)a->nstreams);
@@ -528,21 +570,32 @@ __device__ __noinline__ bool huf_decode_streams(const ZPK_LDS u8* huf, const ZPK
     const i32 top = P - (i32)(((i64)P * j) >> 4), lo = P - (i32)(((i64)P * (j + 1)) >> 4);    // this lane's piece: positions (lo, top]
     HufBits b; b.start = sp; b.rd_hi = rd_hi;
     HufRun r; r.exit = top; r.n = 0; r.m0 = r.m1 = 0;
+    #pragma unroll
+    for (int k = 0; k < HUF_NCP; k++) { r.cp[k] = HUF_CP_NONE; r.cr[k] = 0; }
     i32 entry = top;
     const bool wide = mb <= 11;                                        // uniform: the table holds symbol | length (huf_build)
     if (act) r = wide ? huf_run<0, true>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad)
                       : huf_run<0, false>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad);
+#ifdef ZPK_STATS
+    const u64 t_fix0 = SEQ_T(); u32 n_iter = 0;
+#endif
     for (int iter = 0; iter < 17; iter++) {
         i32 e = __shfl_up(r.exit, 1, 16);
         if (j == 0) e = P;
         const bool changed = act && e != entry;
         if (__ballot(changed) == 0) break;
+#ifdef ZPK_STATS
+        n_iter++;
+#endif
         if (changed) {
             entry = e;
             r = wide ? huf_run<1, true>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad)
                      : huf_run<1, false>(b, huf, rk, mb, entry, lo, top, r, nullptr, deadline, bad);
         }
     }
+#ifdef ZPK_STATS
+    if (a->dbg && lane == 0) { a->dbg[0] += SEQ_T() - t_fix0; a->dbg[1] += n_iter; }
+#endif
     // place the pieces: prefix sum of the symbol counts inside each 16-lane row
     u32 x = act ? r.n : 0u;
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
@@ -853,6 +906,8 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         } else if (!sh.huf_valid) return D_MALFORMED;
         __syncthreads();
         HufArgs ha; ha.p = p; ha.size = left; ha.nstreams = streams; ha.lit = lit_buf; ha.regen = regen; ha.rd_hi = rd_hi; ha.deadline = fs.wd->deadline;
+        ha.dbg = nullptr;
+        ZST(ha.dbg = (u64*)&fs.zs->t_tab);                   // (stats builds: t_tab = cycles in the fix-up rounds, nseq = their number)
         if (!huf_decode_streams(LDSP(u8, sh.huf), LDSP(u32, sh.huf_rank), (int)sh.huf_max_bits, &ha, lane)) return D_MALFORMED;
         wave_mem_fence();
         lit_size = regen; used = hl + csize;
