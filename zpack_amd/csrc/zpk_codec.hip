@@ -4,10 +4,12 @@
 //   1. k_classify   one thread per entry: the guards of zpack_read_file (lib/zpack_read.c:328-332,
 //                   :354, :459) in the reference's order, then the entry index is appended to the
 //                   work list of its method (wave-aggregated atomics).
-//   2. k_stored / k_lz4_wave / k_zstd  persistent grids that pull entries from their work list with an
-//                   atomic dequeue; every wave leaves when the list is drained.
+//   2. k_stored / k_lz4_wave   one wave per work-list slot.
+//   3. k_zstd_fse -> k_zstd_exec -> k_zstd   Zstandard: persistent grids that pull entries from the work list with an
+//                   atomic dequeue (FSE sequence pre-decode four streams per wave; literals + execution + XXH3 of the
+//                   pre-decoded entries; the full decoder for whatever is left over) — zstd_fse4.h, zstd_wg.h.
 // Entries are independent, so there is no inter-workgroup communication besides the
-// dequeue counter.
+// dequeue counters.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -68,17 +70,6 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
         base = (u32)__shfl((int)base, leader, 64);
         if (list == L) lists[(u64)L * list_stride + base + (u32)__popcll(m & ((1ull << lane) - 1))] = (u32)i;
     }
-}
-
-// persistent-grid dequeue (only k_zstd needs a bounded number of workgroups, for its literal scratch)
-__device__ __forceinline__ bool dequeue(u32* counters, int list, int lane, u32& idx)
-{
-    lane0_guard();
-    u32 v = 0;
-    if (lane == 0) v = atomicAdd(&counters[L_COUNT + list], 1u);
-    idx = uni(v);
-    lane0_guard();
-    return idx < uni(counters[list]);
 }
 
 // one wave per work-list slot: the hardware dispatcher is the load balancer
