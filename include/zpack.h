@@ -12,6 +12,12 @@
  *   - the `void* dctx / cctx` handles are OPAQUE codec contexts obtained from zpack_create_dctx /
  *     zpack_create_cctx (the reference let a caller pass a raw ZSTD_DCtx* / LZ4F_dctx* here — that was
  *     never documented and is not supported);
+ *   - contexts: a reader / writer called with dctx / cctx == NULL creates its own context on first use (as the
+ *     reference does, lib/zpack_read.c:17-31) — nothing is shared between two readers, so two readers on two threads
+ *     are independent; buffer-backed reads from N threads on ONE reader are safe when each thread passes its own
+ *     zpack_create_dctx context (lib/zpack.h:337-340); a context shared by threads is serialised, not corrupted.
+ *     With ZPACK_AMD_DEVICES=all (or a list of HIP ordinals) a context spans several GPUs and the batch calls
+ *     (zpack_read_files*, zpack_write_files) shard their entries statically over them;
  *   - if no HIP device is usable, calls that need the codec return ZPACK_ERROR_NOT_AVAILABLE — there is
  *     no CPU fallback;
  *   - two ADDITIVE batch entry points, zpack_read_files / zpack_read_files_packed, mirror
@@ -86,8 +92,10 @@ typedef struct zpack_reader_s {
     zpack_u64 comp_size;
     zpack_u64 uncomp_size;
     size_t file_size;
-    void* zstd_dctx;         /* lazily created codec context (shared by every method) */
-    void* lz4f_dctx;         /* unused: kept for layout compatibility */
+    void* zstd_dctx;         /* this reader's own codec context, created on the first decode with dctx == NULL (every method) */
+    void* lz4f_dctx;         /* PRIVATE: name arena of a reader-owned entry table.  While set, every file_entries[i].filename
+                                points into it: the names are read-only and must not be freed or replaced by the caller;
+                                zpack_close_reader / a second zpack_read_archive* free it.  Do not touch. */
     size_t last_return;      /* codec detail of the last decode (reference: library return value) */
     zpack_u64 cdr_offset;
     zpack_u64 eocdr_offset;
@@ -120,7 +128,7 @@ typedef struct zpack_writer_s {
     zpack_file_entry* file_entries;
     zpack_u64 fe_capacity;
     zpack_u64 file_count;
-    void* zstd_cctx;         /* lazily created codec context (shared by every method) */
+    void* zstd_cctx;         /* this writer's own codec context, created on the first write with cctx == NULL (every method) */
     void* lz4f_cctx;         /* streaming aggregation state */
     size_t last_return;
     zpack_u64 cdr_offset;

@@ -52,6 +52,11 @@ enum {
 /* compression methods — values of zpack_compression_method (zpack.h) */
 enum { ZPK_METHOD_NONE = 0, ZPK_METHOD_ZSTD = 1, ZPK_METHOD_LZ4 = 2 };
 
+/* One codec = one device context with ONE in-flight batch: its work lists, counters and staging buffers are shared by
+ * every call.  Threading contract: the host-pointer entry points (*_host, the streaming triple) hold the codec's lock for
+ * their whole duration — threads sharing a codec are serialised, never corrupted; the device-pointer entry points hold it
+ * while they enqueue, and successive batches on ONE stream are ordered by that stream.  Do not drive one codec from two
+ * streams at once: create one codec per stream / per thread (zpack.h contexts do exactly that). */
 typedef struct zpk_codec zpk_codec;
 
 /* One entry to decode.  Mirrors zpack_file_entry (lib/zpack.h:71-80) + the (buffer, max_size) pair of
@@ -171,6 +176,7 @@ int zpk_codec_timer_stop(zpk_codec* c, void* stream, float* elapsed_ms);   /* sy
  * in avail_out-sized pieces.  Same observable protocol as the reference (total_in/total_out/read_back). */
 typedef struct zpk_dstream zpk_dstream;
 int  zpk_dstream_create(zpk_codec* c, zpk_dstream** out);
+void zpk_dstream_bind(zpk_dstream* s, zpk_codec* c);     /* the codec the NEXT step decodes with (a stream may outlive codecs) */
 void zpk_dstream_reset(zpk_dstream* s);
 void zpk_dstream_destroy(zpk_dstream* s);
 /* feed in_size bytes, receive up to out_cap bytes; *consumed / *produced report progress;
@@ -182,6 +188,7 @@ int  zpk_dstream_step(zpk_dstream* s, uint32_t method, uint64_t entry_comp_size,
 
 typedef struct zpk_cstream zpk_cstream;
 int  zpk_cstream_create(zpk_codec* c, zpk_cstream** out);
+void zpk_cstream_bind(zpk_cstream* s, zpk_codec* c);
 void zpk_cstream_reset(zpk_cstream* s);
 void zpk_cstream_destroy(zpk_cstream* s);
 int  zpk_cstream_update(zpk_cstream* s, const uint8_t* in, size_t in_size);       /* collect plaintext */

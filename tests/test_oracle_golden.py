@@ -84,6 +84,21 @@ def test_recipes_large_frames(golden_dir):
         assert o.xxh3(out) == r["hash"]
 
 
+def test_recipes_big_entries(golden_dir):
+    """the 64 MiB recipes of recipes_big.json (made with the compiled reference): the oracle decodes the same frames to the
+    same bytes and XXH3 (the 512 MiB ones are left to the GPU suite: the CPU suite has to stay short)"""
+    o = oracle()
+    for r in _load(golden_dir, "recipes_big.json"):
+        if r["size"] > (64 << 20) or r["method"] == 0:
+            continue
+        plain = dg.fill(r["cls"], r["seed"], r["index"], r["size"])
+        frame = dg.compress(r["method"], r["level"], plain)
+        assert len(frame) == r["comp_size"] and dg.xxh3(frame) == r["frame_xxh3"], r["label"]
+        dec = o.zstd_decode if r["method"] == 1 else o.lz4f_decode
+        rc, out = dec(frame, r["size"])
+        assert rc == 0 and o.xxh3(out) == r["hash"] and out == plain.tobytes(), r["label"]
+
+
 def test_status_codes_match_reference(golden_dir):
     o = oracle()
     sc = _load(golden_dir, "status_cases.json")

@@ -16,6 +16,7 @@
 #include <string.h>
 #include <new>
 #include <time.h>
+#include <pthread.h>
 
 
 #include "zpk_device.h"
@@ -57,6 +58,9 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
     else if (d.method == ZPK_METHOD_ZSTD) list = L_ZSTD;
     else if (d.method == ZPK_METHOD_LZ4) list = L_LZ4;
     else r.status = R_COMP_METHOD_INVALID;                                     // :459
+    // an entry that goes on a work list is not decoded yet: until its decoder writes the verdict the slot says so
+    // (a decoder that never ran must not read as R_OK)
+    if (list >= 0) { r.status = R_DECOMPRESS_FAILED; r.detail = 0xFFFFFFFFu; }
     if (live) res[i] = r;
     // wave-aggregated append: one atomic per list per wave (a per-lane atomicAdd on three hot words cost 1.1 ms / 100k entries)
     const int lane = lane_id();
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
 // one wave per work-list slot: the hardware dispatcher is the load balancer
 __device__ __forceinline__ bool my_slot(const u32* counters, int list, u32& idx)
 {
-    idx = uni((u32)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    idx = uni((u32)(((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6));           // 64-bit: n blocks x 64 threads passes 2^32 at n = 2^26
     return idx < uni(counters[list]);
 }
 
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
 __global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
-                                                  const u32* __restrict__ counters, u64* __restrict__ dbg, int getenv_dbg2)
+                                                  const u32* __restrict__ counters, u64* __restrict__ dbg)
 {
     const int lane = lane_id();
     __shared__ Lz4WaveShared shw;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, 
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
-        Watchdog wd; wd.arm();
+        Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
         SeqStats stt = {};
         const u64 t_all = SEQ_T(); (void)t_all;
         DecodeOut o = lz4f_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
@@ -168,10 +172,12 @@ __global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, 
             g[0] = stt.t_parse; g[1] = stt.t_lit; g[2] = stt.t_dep; g[3] = stt.t_rounds;
             g[4] = ((u64)stt.batches << 32) | stt.rounds; g[5] = ((u64)stt.coops << 32) | stt.asm_batches; g[6] = SEQ_T() - t_all;
             g[7] = ((u64)stt.fix_iters << 32) | stt.chunks;
-            if (getenv_dbg2) { g[0] = stt.t_stage; g[1] = stt.t_walk1; g[2] = stt.t_fix; g[3] = stt.t_emit; g[4] = stt.t_tok; }
+#ifdef ZPK_STATS_PARSE
+            g[0] = stt.t_stage; g[1] = stt.t_walk1; g[2] = stt.t_fix; g[3] = stt.t_emit; g[4] = stt.t_tok;
+#endif
         }
 #else
-        (void)dbg; (void)getenv_dbg2; (void)t_all;
+        (void)dbg; (void)t_all;
 #endif
         // lib/zpack_read.c:421-450
         int status = R_OK;
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
         const u64* const pre = arena + (((u64)d.dst_offset + 7) >> 3);
-        Watchdog wd; wd.arm();
+        Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
 #ifdef ZPK_STATS
         ZstdStats zs = {};
         const u64 t_all = SEQ_T();
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restric
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
-        Watchdog wd; wd.arm();
+        Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
 #ifdef ZPK_STATS
         ZstdStats zs = {};
         const u64 t_all = SEQ_T();
@@ -318,6 +324,12 @@ __global__ __launch_bounds__(256) void k_hash(const u8* __restrict__ src, const 
 struct zpk_codec {
     int device = 0;
     hipStream_t stream = nullptr;
+    // One codec = one in-flight batch: the work lists, counters and staging buffers below are shared by every call.
+    // The host-pointer entry points (decode/encode_batch_host, hash_host, the streaming triple) take `mu` for their
+    // whole duration, so threads that share a codec are serialised, never corrupted.  The device-pointer entry points
+    // take it only while they enqueue: batches on ONE stream are ordered by the stream; a codec must not be driven
+    // from two streams at once (create one codec per stream — contexts are cheap).
+    pthread_mutex_t mu;
     u32* d_counters = nullptr;
     u32* d_lists = nullptr;      u64 list_cap = 0;
     u8*  d_lit = nullptr;        u64 lit_cap = 0;
@@ -336,7 +348,17 @@ struct zpk_codec {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t kev[ZPK_K_COUNT][2] = {};
     int profiling = 0;
+    int zstd_hint = -1;          // host path: does the batch hold a Zstandard entry (1 / 0)?  -1 = unknown (device path)
+    int fell_back_fused = 0;     // the last decode batch could not get its sequence arena and ran the fused decoder only
     char err[256] = {0};
+};
+
+struct CodecLock {
+    pthread_mutex_t* m;
+    explicit CodecLock(zpk_codec* c) : m(&c->mu) { pthread_mutex_lock(m); }
+    ~CodecLock() { pthread_mutex_unlock(m); }
+    CodecLock(const CodecLock&) = delete;
+    CodecLock& operator=(const CodecLock&) = delete;
 };
 
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -345,9 +367,17 @@ struct zpk_codec {
 static int grow(zpk_codec* c, void** p, u64* cap, u64 need)
 {
     if (need <= *cap) return ZPK_OK;
-    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    // the buffer may still be in use by work enqueued earlier on the codec's stream or the caller's
+    if (*p) { (void)hipDeviceSynchronize(); (void)hipFree(*p); *p = nullptr; *cap = 0; }
     u64 want = need + need / 4 + 4096;
-    if (hipMalloc(p, want) != hipSuccess) { snprintf(c->err, sizeof(c->err), "hipMalloc(%llu) failed", (unsigned long long)want); return ZPK_E_NOMEM; }
+    if (hipMalloc(p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        want = need + 256;                                                          // the slack was a convenience, not a need
+        if (hipMalloc(p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            snprintf(c->err, sizeof(c->err), "hipMalloc(%llu) failed", (unsigned long long)want); return ZPK_E_NOMEM;
+        }
+    }
     *cap = want;
     return ZPK_OK;
 }
@@ -379,10 +409,14 @@ int zpk_codec_create(zpk_codec** out, int device)
     zpk_codec* c = new (std::nothrow) zpk_codec();
     if (!c) return ZPK_E_NOMEM;
     c->device = device;
+    {   // recursive: the host entry points call the device ones underneath
+        pthread_mutexattr_t at; pthread_mutexattr_init(&at); pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
+        pthread_mutex_init(&c->mu, &at); pthread_mutexattr_destroy(&at);
+    }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, N_COUNTERS * sizeof(u32)) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
-        delete c;
+        zpk_codec_destroy(c);
         return ZPK_E_NO_DEVICE;
     }
     *out = c;
@@ -400,34 +434,56 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
+    pthread_mutex_destroy(&c->mu);
     delete c;
 }
 
-void zpk_codec_reset(zpk_codec* c) { if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); c->err[0] = 0; } }
+// after an abandoned stream / a failed call (the reference resets its library context: lib/zpack_read.c:679-690): wait for
+// whatever the codec still has in flight and forget the last error; every later call starts from a clean context
+void zpk_codec_reset(zpk_codec* c)
+{
+    if (!c) return;
+    CodecLock lk(c);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+    c->err[0] = 0;
+}
 const char* zpk_codec_last_error(const zpk_codec* c) { return c ? c->err : "no codec"; }
 int zpk_codec_device(const zpk_codec* c) { return c ? c->device : -1; }
+
+// Developer hooks (ZPK_TRACE / ZPK_SKIP / ZPK_DEBUG_TIMING environment switches) exist only in a -DZPK_DEVELOPER build:
+// the product launch path reads no environment and can neither drop a kernel nor end the host process.
+#ifdef ZPK_DEVELOPER
+#define ZPK_DEV(x) x
+#else
+#define ZPK_DEV(x)
+#endif
 
 static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* read_lo, const u8* read_hi,
                          const zpk_decode_desc* desc, u64 n, u8* dst, u64 dst_size, zpk_decode_result* res, hipStream_t st)
 {
     if (n == 0) return ZPK_OK;
-    if (n > 0xFFFFFFF0ull) return ZPK_E_INVALID;
+    if (n > 0x7FFFFFF0ull) return ZPK_E_INVALID;               // one workgroup per LZ4 entry: the grid's x limit
     int rc;
     if ((rc = grow(c, (void**)&c->d_lists, &c->list_cap, N_LISTS * n * sizeof(u32)))) return rc;
     const u64 stride = c->list_cap / (N_LISTS * sizeof(u32));
+    int skip = 0; (void)skip;
+#ifdef ZPK_DEVELOPER
     static const int want_dbg = getenv("ZPK_DEBUG_TIMING") ? atoi(getenv("ZPK_DEBUG_TIMING")) : 0;
     if (want_dbg) { if ((rc = grow(c, (void**)&c->d_dbg, &c->dbg_cap, n * 64))) return rc; }
-    const u32 zstd_grid = (u32)(n < ZSTD_GRID_MAX ? n : ZSTD_GRID_MAX);
-    if ((rc = grow(c, (void**)&c->d_lit, &c->lit_cap, (u64)ZSTD_EXEC_GRID_MAX * ZSTD_LIT_SCRATCH))) return rc;
-    // debugging aids: ZPK_TRACE=1 synchronises and reports after every launch, ZPK_SKIP=<bitmask> leaves
-    // kernels out (1 stored, 2 lz4, 4 zstd)
     static const int trace = getenv("ZPK_TRACE") ? atoi(getenv("ZPK_TRACE")) : 0;
-    static const int skip = getenv("ZPK_SKIP") ? atoi(getenv("ZPK_SKIP")) : 0;
-    static hipEvent_t tev[8]; static int tev_n = 0; static const char* tev_name[8];
-    if (trace == 2) { tev_n = 0; for (int i = 0; i < 8; i++) if (!tev[i]) (void)hipEventCreate(&tev[i]); }
+    static const int skip_env = getenv("ZPK_SKIP") ? atoi(getenv("ZPK_SKIP")) : 0;      // bitmask: 1 stored, 2 lz4, 4 zstd
+    skip = skip_env;
 #define ZPK_TRACE_STEP(name) do { if (trace == 1) { hipError_t te_ = hipStreamSynchronize(st); \
-        fprintf(stderr, "[zpk] %s done: %s\n", name, hipGetErrorString(te_)); fflush(stderr); } \
-        else if (trace == 2) { tev_name[tev_n] = name; (void)hipEventRecord(tev[tev_n++], st); } } while (0)
+        fprintf(stderr, "[zpk] %s done: %s\n", name, hipGetErrorString(te_)); fflush(stderr); } } while (0)
+#else
+#define ZPK_TRACE_STEP(name) do { } while (0)
+#endif
+    const u32 zstd_grid = (u32)(n < ZSTD_GRID_MAX ? n : ZSTD_GRID_MAX);
+    const u32 exec_grid = (u32)(n < ZSTD_EXEC_GRID_MAX ? n : ZSTD_EXEC_GRID_MAX);
+    const bool maybe_zstd = c->zstd_hint != 0;                  // the host path knows its methods; device batches may hold any
+    if (maybe_zstd && (rc = grow(c, (void**)&c->d_lit, &c->lit_cap, (u64)(exec_grid > zstd_grid ? exec_grid : zstd_grid) * ZSTD_LIT_SCRATCH))) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(u32), st));
     ZPK_TRACE_STEP("memset");
 #define ZPK_KEV(k, j) do { if (c->profiling) (void)hipEventRecord(c->kev[k][j], st); } while (0)
@@ -443,16 +499,22 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_TRACE_STEP("k_stored");
     ZPK_KEV(ZPK_K_LZ4, 0);
     if (!(skip & 2)) hipLaunchKernelGGL(k_lz4_wave, dim3((u32)n), dim3(64), 0, st, src, read_lo, read_hi, desc, dst, res,
-                       c->d_lists + L_LZ4 * stride, c->d_counters, c->d_dbg, want_dbg == 2 ? 1 : 0);
+                       c->d_lists + L_LZ4 * stride, c->d_counters, c->d_dbg);
     ZPK_KEV(ZPK_K_LZ4, 1);
     ZPK_TRACE_STEP("k_lz4_wave");
     // Zstandard in two stages: the FSE sequence streams four per wave into an arena laid out like dst (8 bytes per
     // sequence: room for one sequence per 8 output bytes; entries that need more stay with the fused decoder), then
-    // literals + execution + checksum.  Without the arena (allocation refused, ZPK_ZSTD_FUSED=1) k_zstd does it all.
-    static const int fused_only = getenv("ZPK_ZSTD_FUSED") ? atoi(getenv("ZPK_ZSTD_FUSED")) : 0;
-    bool two_stage = !fused_only && dst_size >= 64;
+    // literals + execution + checksum.  Without the arena (allocation refused) k_zstd does it all, and the codec says so
+    // (zpk_codec_decode_stats out[7] bit 31, zpk_codec_last_error).
+    bool two_stage = maybe_zstd && dst_size >= 64;
+    ZPK_DEV(static const int fused_only = getenv("ZPK_ZSTD_FUSED") ? atoi(getenv("ZPK_ZSTD_FUSED")) : 0; if (fused_only) two_stage = false;)
+    c->fell_back_fused = 0;
     if (two_stage && (grow(c, (void**)&c->d_zarena, &c->zarena_cap, dst_size + 64) != ZPK_OK ||
-                      grow(c, (void**)&c->d_zstate, &c->zstate_cap, 2 * n * sizeof(u32)) != ZPK_OK)) { two_stage = false; c->err[0] = 0; }
+                      grow(c, (void**)&c->d_zstate, &c->zstate_cap, 2 * n * sizeof(u32)) != ZPK_OK)) {
+        two_stage = false; c->fell_back_fused = 1;
+        snprintf(c->err, sizeof(c->err), "note: no memory for the %llu-byte Zstandard sequence arena; this batch ran the fused decoder",
+                 (unsigned long long)dst_size + 64);
+    }
     u32* const leftover = two_stage ? c->d_zstate + n : nullptr;          // entries k_zstd_exec hands to the full decoder
     ZPK_KEV(ZPK_K_ZSTD_FSE, 0);
     if (!(skip & 4) && two_stage) {
@@ -465,28 +527,14 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_TRACE_STEP("k_zstd_fse");
     ZPK_KEV(ZPK_K_ZSTD, 0);
     if (!(skip & 4) && two_stage)
-        hipLaunchKernelGGL(k_zstd_exec, dim3((u32)(n < ZSTD_EXEC_GRID_MAX ? n : ZSTD_EXEC_GRID_MAX)), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
+        hipLaunchKernelGGL(k_zstd_exec, dim3(exec_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
                            c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_zarena, c->d_zstate, leftover, c->d_dbg);
-    if (!(skip & 4)) hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
+    if (!(skip & 4) && maybe_zstd)
+        hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
                        two_stage ? (const u32*)leftover : (const u32*)(c->d_lists + L_ZSTD * stride), c->d_counters, c->d_lit, c->d_dbg,
                        two_stage ? (int)C_LEFT_COUNT : (int)L_ZSTD);
     ZPK_KEV(ZPK_K_ZSTD, 1);
     ZPK_TRACE_STEP("k_zstd");
-    if (trace == 2) {
-        for (int spin = 0; spin < 100; spin++) {
-            bool all = true;
-            for (int i = 0; i < tev_n; i++) if (hipEventQuery(tev[i]) != hipSuccess) all = false;
-            if (all) break;
-            struct timespec ts = { 0, 100000000 }; nanosleep(&ts, nullptr);
-        }
-        for (int i = 0; i < tev_n; i++)
-            fprintf(stderr, "[zpk] after 10s: %-12s %s\n", tev_name[i], hipEventQuery(tev[i]) == hipSuccess ? "done" : "NOT DONE");
-        u32 hc[16];
-        if (hipEventQuery(tev[tev_n - 1]) != hipSuccess) { fflush(stderr); _Exit(3); }
-        (void)hipMemcpy(hc, c->d_counters, 64, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[zpk] counters: count %u %u %u head %u %u %u\n", hc[0], hc[1], hc[2], hc[4], hc[5], hc[6]);
-        fflush(stderr);
-    }
     HIPCHK(c, hipGetLastError());
     return ZPK_OK;
 }
@@ -495,71 +543,121 @@ int zpk_codec_decode_batch_device(zpk_codec* c, const uint8_t* src, uint64_t src
                                   uint8_t* dst, uint64_t dst_size, zpk_decode_result* results, void* stream)
 {
     if (!c || (n && (!desc || !results))) return ZPK_E_INVALID;
+    CodecLock lk(c);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->zstd_hint = -1;
     return decode_launch(c, src, src_size, src, src + src_size, desc, n, dst, dst_size, results, st);
 }
+
+// One sub-batch of the host path: entries [0, n) of hd/desc, whose slots (hd[i].dst_offset, already laid out) total
+// out_total bytes.  `image` is what gets staged: either the archive itself (span mode, src_offset = archive offsets,
+// staged range [lo, hi)) or a packed copy of just these payloads (gather mode: hd[i].src_offset already rewritten).
+static int decode_host_chunk(zpk_codec* c, const u8* image, u64 image_size, u64 lo, u64 hi, zpk_decode_desc* hd,
+                             const zpk_decode_desc* desc, u64 n, u64 out_total, uint8_t* const* dst_ptrs, zpk_decode_result* results)
+{
+    int rc;
+    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, hi - lo + 16)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, out_total + 16)) ||
+        (rc = grow(c, &c->d_desc, &c->desc_cap, n * sizeof(zpk_decode_desc))) ||
+        (rc = grow(c, &c->d_res, &c->res_cap, n * sizeof(zpk_decode_result)))) return rc;
+    hipError_t e = hipSuccess;
+    if (hi > lo) e = hipMemcpyAsync(c->d_src, image + lo, hi - lo, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_desc, hd, n * sizeof(zpk_decode_desc), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    // base pointer such that base + src_offset lands in the staged range; reads are clamped to it
+    const u8* base = c->d_src - lo;
+    rc = decode_launch(c, base, image_size, c->d_src, c->d_src + (hi - lo), (const zpk_decode_desc*)c->d_desc, n,
+                       c->d_dst, out_total, (zpk_decode_result*)c->d_res, c->stream);
+    if (rc) return rc;
+    e = hipMemcpyAsync(results, c->d_res, n * sizeof(zpk_decode_result), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "decode: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    // hand the bytes back: everything the codec produced (a hash mismatch leaves the data in the buffer, like the
+    // reference), and only that — a generous max_size costs device address space, not PCIe time
+    u64 produced_total = 0;
+    for (u64 i = 0; i < n; i++) {
+        if (results[i].produced > desc[i].dst_capacity) results[i].produced = desc[i].dst_capacity;     // (cannot happen)
+        produced_total += results[i].produced;
+    }
+    if (n > 1 && produced_total && produced_total * 2 >= out_total) {                   // dense: one transfer, then a host scatter
+        u8* tmp = (u8*)malloc(out_total);
+        if (!tmp) return ZPK_E_NOMEM;
+        e = hipMemcpy(tmp, c->d_dst, out_total, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (u64 i = 0; i < n; i++) if (results[i].produced) memcpy(dst_ptrs[i], tmp + hd[i].dst_offset, results[i].produced);
+        free(tmp);
+    } else {
+        for (u64 i = 0; i < n && e == hipSuccess; i++)
+            if (results[i].produced) e = hipMemcpy(dst_ptrs[i], c->d_dst + hd[i].dst_offset, results[i].produced, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "D2H: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    return ZPK_OK;
+}
+
+#ifndef ZPK_HOST_CHUNK_BYTES
+#define ZPK_HOST_CHUNK_BYTES (4ull << 30)        // output slots of one device sub-batch of the host path (an entry larger than this goes alone)
+#endif
 
 int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t archive_size, const zpk_decode_desc* desc, uint64_t n,
                                 uint8_t* const* dst_ptrs, zpk_decode_result* results)
 {
     if (!c || (n && (!desc || !results || !dst_ptrs))) return ZPK_E_INVALID;
     if (n == 0) return ZPK_OK;
+    CodecLock lk(c);
     HIPCHK(c, hipSetDevice(c->device));
-    // byte range of the archive the batch can touch (entries failing the offset guard touch nothing)
-    u64 lo = ~0ull, hi = 0, out_total = 0;
     zpk_decode_desc* hd = (zpk_decode_desc*)malloc(n * sizeof(zpk_decode_desc));
     if (!hd) return ZPK_E_NOMEM;
-    for (u64 i = 0; i < n; i++) {
-        hd[i] = desc[i];
-        const zpk_decode_desc& d = desc[i];
-        bool ok = d.comp_size && d.src_offset <= archive_size && d.comp_size <= archive_size - d.src_offset;
-        if (ok) { if (d.src_offset < lo) lo = d.src_offset; if (d.src_offset + d.comp_size > hi) hi = d.src_offset + d.comp_size; }
-        hd[i].dst_offset = out_total;
-        out_total += (d.dst_capacity + 255) & ~255ull;
-    }
-    if (lo > hi) { lo = 0; hi = 0; }
-    int rc;
-    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, hi - lo + 16)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, out_total + 16)) ||
-        (rc = grow(c, &c->d_desc, &c->desc_cap, n * sizeof(zpk_decode_desc))) ||
-        (rc = grow(c, &c->d_res, &c->res_cap, n * sizeof(zpk_decode_result)))) { free(hd); return rc; }
-    hipError_t e = hipSuccess;
-    if (hi > lo) e = hipMemcpyAsync(c->d_src, archive + lo, hi - lo, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(c->d_desc, hd, n * sizeof(zpk_decode_desc), hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) { free(hd); snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
-    // base pointer such that base + src_offset lands in the staged range; reads are clamped to it
-    const u8* base = c->d_src - lo;
-    const bool crumbs = getenv("ZPK_TRACE") && atoi(getenv("ZPK_TRACE")) == 3;
-#define CRUMB(msg) do { if (crumbs) { fprintf(stderr, "[zpk] %s\n", msg); fflush(stderr); } } while (0)
-    CRUMB("H2D queued");
-    rc = decode_launch(c, base, archive_size, c->d_src, c->d_src + (hi - lo), (const zpk_decode_desc*)c->d_desc, n,
-                       c->d_dst, out_total, (zpk_decode_result*)c->d_res, c->stream);
-    if (rc) { free(hd); return rc; }
-    CRUMB("kernels queued");
-    e = hipMemcpyAsync(results, c->d_res, n * sizeof(zpk_decode_result), hipMemcpyDeviceToHost, c->stream);
-    CRUMB("results D2H queued");
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    CRUMB("stream synchronised");
-    if (e != hipSuccess) { free(hd); snprintf(c->err, sizeof(c->err), "decode: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
-    // hand the bytes back: everything the codec produced (hash mismatch leaves data in the buffer, like the reference)
-    if (n == 1) {
-        u64 nb = results[0].produced; if (nb > desc[0].dst_capacity) nb = desc[0].dst_capacity;
-        if (nb) e = hipMemcpy(dst_ptrs[0], c->d_dst, nb, hipMemcpyDeviceToHost);
-    } else {
-        u8* tmp = (u8*)malloc(out_total ? out_total : 1);
-        if (!tmp) { free(hd); return ZPK_E_NOMEM; }
-        e = hipMemcpy(tmp, c->d_dst, out_total, hipMemcpyDeviceToHost);
-        if (e == hipSuccess)
-            for (u64 i = 0; i < n; i++) {
-                u64 nb = results[i].produced; if (nb > desc[i].dst_capacity) nb = desc[i].dst_capacity;
-                if (nb) memcpy(dst_ptrs[i], tmp + hd[i].dst_offset, nb);
+    int rc = ZPK_OK;
+    u8* gathered = nullptr; u64 gathered_cap = 0;
+    for (u64 first = 0; first < n && rc == ZPK_OK; ) {
+        // ---- cut a sub-batch by the size of its output slots ----
+        u64 out_total = 0, cnt = 0, lo = ~0ull, hi = 0, comp_sum = 0;
+        int has_zstd = 0;
+        while (first + cnt < n) {
+            const zpk_decode_desc& d = desc[first + cnt];
+            // stored entries copy exactly uncomp_size bytes (lib/zpack_read.c:366); the decoders may fill all of max_size
+            const u64 slot_bytes = d.method == ZPK_METHOD_NONE && d.uncomp_size < d.dst_capacity ? d.uncomp_size : d.dst_capacity;
+            const u64 slot = (slot_bytes + 255) & ~255ull;
+            if (cnt && (out_total + slot > ZPK_HOST_CHUNK_BYTES || cnt >= 0x7FFFFFF0ull)) break;
+            hd[first + cnt] = d;
+            hd[first + cnt].dst_offset = out_total;
+            // (the device still judges `max_size < uncomp_size` on the caller's capacity: dst_capacity stays as given
+            // except for stored entries, whose slot is the smaller of the two and whose guard passed or failed on the host values)
+            if (d.method == ZPK_METHOD_NONE && d.dst_capacity >= d.uncomp_size) hd[first + cnt].dst_capacity = slot_bytes;
+            out_total += slot;
+            const bool ok = d.comp_size && d.src_offset <= archive_size && d.comp_size <= archive_size - d.src_offset;
+            if (ok) { if (d.src_offset < lo) lo = d.src_offset; if (d.src_offset + d.comp_size > hi) hi = d.src_offset + d.comp_size; comp_sum += d.comp_size; }
+            if (d.method == ZPK_METHOD_ZSTD) has_zstd = 1;
+            cnt++;
+        }
+        if (lo > hi) { lo = 0; hi = 0; }
+        c->zstd_hint = has_zstd;
+        const u8* image = archive; u64 image_size = archive_size;
+        if (hi - lo > 2 * comp_sum + (1u << 20)) {
+            // sparse picks out of a large archive: stage only the payloads.  Entries that pass the reference's offset guard
+            // (lib/zpack_read.c:331) are packed behind each other, followed by one pad byte so that the guard still passes;
+            // the others get an offset that still fails it — the device evaluates the same guards in the same order.
+            const u64 total = comp_sum + 1;
+            if (total + 1 > gathered_cap) { free(gathered); gathered = (u8*)malloc(total + 1); gathered_cap = gathered ? total + 1 : 0; }
+            if (!gathered) { rc = ZPK_E_NOMEM; break; }
+            u64 pos = 0;
+            for (u64 i = first; i < first + cnt; i++) {
+                const zpk_decode_desc& d = desc[i];
+                const bool in_image = d.comp_size && d.src_offset <= archive_size && d.comp_size <= archive_size - d.src_offset;
+                const bool passes = in_image && d.src_offset + d.comp_size < archive_size;
+                if (passes) { memcpy(gathered + pos, archive + d.src_offset, d.comp_size); hd[i].src_offset = pos; pos += d.comp_size; }
+                else hd[i].src_offset = total + 1;
             }
-        free(tmp);
+            gathered[pos] = 0;
+            image = gathered; image_size = total; lo = 0; hi = pos;
+        }
+        rc = decode_host_chunk(c, image, image_size, lo, hi, hd + first, desc + first, cnt, out_total, dst_ptrs + first, results + first);
+        first += cnt;
     }
-    CRUMB("payload D2H done");
+    c->zstd_hint = -1;
+    free(gathered);
     free(hd);
-    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "D2H: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
-    return ZPK_OK;
+    return rc;
 }
 
 int zpk_codec_hash_batch_device(zpk_codec* c, const uint8_t* src, const uint64_t* offsets, const uint64_t* sizes, uint64_t n,
@@ -567,6 +665,7 @@ int zpk_codec_hash_batch_device(zpk_codec* c, const uint8_t* src, const uint64_t
 {
     if (!c) return ZPK_E_INVALID;
     if (n == 0) return ZPK_OK;
+    CodecLock lk(c);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     hipLaunchKernelGGL(k_hash, dim3((u32)((n + 3) / 4)), dim3(256), 0, st, src, offsets, sizes, n, hashes);
@@ -577,6 +676,7 @@ int zpk_codec_hash_batch_device(zpk_codec* c, const uint8_t* src, const uint64_t
 int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64_t* hash)
 {
     if (!c || !hash) return ZPK_E_INVALID;
+    CodecLock lk(c);
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, size + 16)) || (rc = grow(c, &c->d_res, &c->res_cap, 64))) return rc;
@@ -593,7 +693,7 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
 // debugging: copy the per-entry phase timing words (8 x u64 per entry; needs ZPK_DEBUG_TIMING=1) to the host
 int zpk_codec_debug_read(zpk_codec* c, void* host, uint64_t bytes)
 {
-    if (!c || !c->d_dbg || bytes > c->dbg_cap) return ZPK_E_INVALID;
+    if (!c || !c->d_dbg || bytes > c->dbg_cap) return ZPK_E_INVALID;      // d_dbg exists only in a -DZPK_DEVELOPER build
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(host, c->d_dbg, bytes, hipMemcpyDeviceToHost));
     return ZPK_OK;
@@ -610,7 +710,8 @@ int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8])
     HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[L_NONE]; out[1] = h[L_ZSTD]; out[2] = h[L_LZ4]; out[3] = h[C_ZSTD_TWO_STAGE]; out[4] = h[C_ZSTD_FUSED];
     out[5] = h[ZF_WATCHDOG_WORD]; out[6] = h[ZF_WATCHDOG_WORD + 1]; out[7] = h[13];
-    if (getenv("ZPK_TRACE")) fprintf(stderr, "[zpk] fse marked %u, pass-0 failures %u, last failure status/rc %08x\n", h[13], h[14], h[15]);
+    if (c->fell_back_fused) out[7] |= 0x80000000u;          // the batch could not get its sequence arena: fused decoder only
+    ZPK_DEV(if (getenv("ZPK_TRACE")) fprintf(stderr, "[zpk] fse marked %u, pass-0 failures %u, last failure status/rc %08x\n", h[13], h[14], h[15]);)
     return ZPK_OK;
 }
 

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
     const u32 tmask = chain ? 511u : 0u;                 // idle lanes read cell 0
     u32 badv = 0;
     const u32 nz = counters[ZF_COUNT_WORD];
-    // A row must never hold the GPU: an entry gets ZPK_WATCHDOG_SECONDS (like the fused decoder), and the header
+    // A row must never hold the GPU: an entry gets the size-proportional budget of zpk_device.h (like the fused decoder), and the header
     // loop a fixed budget of steps per wave; either limit just hands the entry (or the rest of the list) to k_zstd.
     u64 row_deadline = 0;
     u32 setup_steps = 0;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                     const u64 cap = hi8 > lo8 ? (hi8 - lo8) >> 3 : 0;
                     seq_cap = cap > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)cap;
                     seq_n = 0; bad = false; badv = 0;
-                    row_deadline = __builtin_amdgcn_s_memrealtime() + (u64)ZPK_WATCHDOG_SECONDS * 100000000ull;
+                    row_deadline = __builtin_amdgcn_s_memrealtime() + watchdog_budget(d.comp_size + d.dst_capacity);
                     phase = ZF_NEED_FRAME;
                 }
                 if (phase == ZF_NEED_FRAME) {

@@ -22,11 +22,20 @@ static inline void zi_put64(zpack_u8* p, zpack_u64 v) { for (int i = 0; i < 8; i
 #define zi_fseek(fp, off, whence) fseeko((fp), (off_t)(off), (whence))
 #define zi_ftell(fp) ((zpack_u64)ftello(fp))
 
-/* the process-wide default codec context (created on first use, never a CPU fallback);
- * returns NULL when no HIP device is usable */
-zpk_codec* zi_default_codec(void);
-/* resolve the codec for a call: explicit context, else the owner's cached one, else the default */
-zpk_codec* zi_pick_codec(void* explicit_ctx, void** owner_slot);
+/* a context = the device codecs a reader / writer / explicit dctx / cctx works with (util.c) */
+#define ZI_MAX_DEVICES 16
+typedef struct zi_ctx_s { int n; zpk_codec* dev[ZI_MAX_DEVICES]; } zi_ctx;
+zi_ctx* zi_ctx_create(void);                 /* NULL when no HIP device is usable: there is no CPU fallback */
+void    zi_ctx_destroy(zi_ctx* x);
+void    zi_ctx_reset(zi_ctx* x);
+/* resolve the context of a call: the explicit one, else the owner's (created on first use, freed by zpack_close_*) */
+zi_ctx* zi_pick_ctx(void* explicit_ctx, void** owner_slot);
+/* contiguous split of `count` weighted items into `parts` ranges: cut[0..parts] */
+void zi_split(const zpack_u64* w, zpack_u64 count, int parts, zpack_u64* cut);
+void zi_parallel(int parts, void (*fn)(void*, int), void* arg);
+/* name index of reader-owned entry tables (zpack_get_file_entry) */
+void zi_index_register(const zpack_file_entry* table, zpack_u64 count);
+void zi_index_drop(const zpack_file_entry* table);
 
 /* per-stream aggregation state hung off zpack_stream.xxh3_state */
 typedef struct zi_stream_state_s {

@@ -68,6 +68,17 @@ int zpack_read_cdr_header_memory(const zpack_u8* buffer, zpack_u64* count, zpack
     return ZPACK_OK;
 }
 
+/* The reference reads the 20-byte CDR header at cdr_offset after checking only cdr_offset < file_size
+ * (lib/zpack_read.c:249-250), i.e. up to 19 bytes past the buffer.  Same verdicts where the reference's are defined
+ * (a readable, wrong signature is SIGNATURE_INVALID), no out-of-bounds read where they are not. */
+static int cdr_header_bounded(const zpack_u8* buffer, size_t size_left, zpack_u64* count, zpack_u64* block_size)
+{
+    if (size_left < ZPACK_SIGNATURE_SIZE) return ZPACK_ERROR_SIGNATURE_INVALID;
+    if (!sig_is(buffer, ZPACK_CDR_SIGNATURE)) return ZPACK_ERROR_SIGNATURE_INVALID;
+    if (size_left < ZPACK_CDR_HEADER_SIZE) return ZPACK_ERROR_BLOCK_SIZE_INVALID;
+    return zpack_read_cdr_header_memory(buffer, count, block_size);
+}
+
 /* one CDR record: u16 name length, name (no NUL), offset, comp_size, uncomp_size, hash, method */
 int zpack_read_file_entry_memory(const zpack_u8* buffer, zpack_u64* size_left, zpack_file_entry* entry, size_t* entry_size)
 {
@@ -114,7 +125,7 @@ int zpack_read_cdr_memory(const zpack_u8* buffer, size_t size_left, zpack_file_e
                           zpack_u64* total_cs, zpack_u64* total_us)
 {
     zpack_u64 n = 0, block = 0;
-    int rc = zpack_read_cdr_header_memory(buffer, &n, &block);
+    int rc = cdr_header_bounded(buffer, size_left, &n, &block);
     if (rc) return rc;
     if (block > (zpack_u64)size_left || ZPACK_CDR_HEADER_SIZE + block > (zpack_u64)size_left) return ZPACK_ERROR_BLOCK_SIZE_INVALID;
     if (n == 0) return ZPACK_OK;
@@ -140,13 +151,27 @@ int zpack_read_cdr(FILE* fp, zpack_u64 cdr_offset, zpack_file_entry** entries, z
 
 /* CDR -> reader-owned entry table, with ALL filenames in one allocation (at 1 M entries the
  * reference's malloc + memcpy per name, lib/zpack_read.c:109-134, is the visible serial cost once decode is fast).
- * The arena hangs off reader->lz4f_dctx, a field this implementation has no other use for; zpack_close_reader frees
- * it instead of the individual names.  The public zpack_read_cdr* / zpack_read_file_entries_memory keep the
+ * The arena hangs off reader->lz4f_dctx (documented in zpack.h: "name arena of a reader-owned table"); while it is set,
+ * every filename of reader->file_entries points into it, the names are read-only, and zpack_close_reader / a re-parse
+ * free the arena instead of the individual names.  The public zpack_read_cdr* / zpack_read_file_entries_memory keep the
  * reference's one-malloc-per-name contract for callers that own their tables. */
+static void reader_drop_table(zpack_reader* reader)
+{
+    if (reader->file_entries) {
+        zi_index_drop(reader->file_entries);
+        if (!reader->lz4f_dctx)
+            for (zpack_u64 i = 0; i < reader->file_count; i++) free(reader->file_entries[i].filename);
+        free(reader->file_entries);
+    }
+    free(reader->lz4f_dctx);
+    reader->file_entries = NULL; reader->lz4f_dctx = NULL;
+    reader->file_count = 0; reader->comp_size = 0; reader->uncomp_size = 0;
+}
+
 static int reader_load_entries(zpack_reader* reader, const zpack_u8* cdr, size_t size_left)
 {
     zpack_u64 n = 0, block = 0;
-    int rc = zpack_read_cdr_header_memory(cdr, &n, &block);
+    int rc = cdr_header_bounded(cdr, size_left, &n, &block);
     if (rc) return rc;
     if (block > (zpack_u64)size_left || ZPACK_CDR_HEADER_SIZE + block > (zpack_u64)size_left) return ZPACK_ERROR_BLOCK_SIZE_INVALID;
     if (n == 0) return ZPACK_OK;
@@ -168,6 +193,7 @@ static int reader_load_entries(zpack_reader* reader, const zpack_u8* cdr, size_t
     if (!table || !arena) { free(arena); if (table) reader->file_entries = table; return ZPACK_ERROR_MALLOC_FAILED; }
     reader->file_entries = table;
     reader->lz4f_dctx = arena;
+    zi_index_register(table, n);
     /* pass 2 */
     p = body;
     char* w = arena;
@@ -201,7 +227,8 @@ int zpack_read_archive_memory(zpack_reader* reader)
     reader->eocdr_offset = reader->file_size - ZPACK_EOCDR_SIZE;
     if ((rc = zpack_read_eocdr_memory(a + reader->eocdr_offset, &reader->cdr_offset))) return rc;
     if (reader->cdr_offset >= reader->file_size) return ZPACK_ERROR_READ_FAILED;
-    if (reader->file_entries || reader->lz4f_dctx)        /* a table from an earlier (public-API) parse: keep its contract */
+    if (reader->lz4f_dctx) reader_drop_table(reader);     /* an arena table from an earlier parse of this reader: start over */
+    if (reader->file_entries)                             /* a table the caller put there (public-API parse): keep its contract */
         return zpack_read_cdr_memory(a + reader->cdr_offset, reader->file_size - (size_t)reader->cdr_offset, &reader->file_entries,
                                      &reader->file_count, &reader->comp_size, &reader->uncomp_size);
     return reader_load_entries(reader, a + reader->cdr_offset, reader->file_size - (size_t)reader->cdr_offset);
@@ -218,7 +245,8 @@ int zpack_read_archive(zpack_reader* reader)
     if ((rc = zpack_read_data_header(reader->file))) return rc;
     reader->eocdr_offset = reader->file_size - ZPACK_EOCDR_SIZE;
     if ((rc = zpack_read_eocdr(reader->file, reader->eocdr_offset, &reader->cdr_offset))) return rc;
-    if (reader->file_entries || reader->lz4f_dctx)
+    if (reader->lz4f_dctx) reader_drop_table(reader);
+    if (reader->file_entries)
         return zpack_read_cdr(reader->file, reader->cdr_offset, &reader->file_entries, &reader->file_count,
                               &reader->comp_size, &reader->uncomp_size);
     {   /* the whole CDR in one read, then the arena parse */
@@ -279,6 +307,18 @@ static void fill_desc(zpk_decode_desc* d, const zpack_file_entry* e, zpack_u64 s
     d->method = e->comp_method;
 }
 
+typedef struct {
+    zi_ctx* ctx; const zpack_u8* image; zpack_u64 image_size; const zpk_decode_desc* desc; zpack_u8* const* buffers;
+    zpk_decode_result* res; zpack_u64 cut[ZI_MAX_DEVICES + 1]; int rc[ZI_MAX_DEVICES];
+} read_job;
+
+static void read_part(void* arg, int k)
+{
+    read_job* j = (read_job*)arg;
+    const zpack_u64 lo = j->cut[k], n = j->cut[k + 1] - lo;
+    j->rc[k] = n ? zpk_codec_decode_batch_host(j->ctx->dev[k], j->image, j->image_size, j->desc + lo, n, j->buffers + lo, j->res + lo) : ZPK_OK;
+}
+
 /* n entries in ONE device batch.  Memory-backed readers hand the codec the archive image itself
  * (zero-copy on the host side, as the reference does at lib/zpack_read.c:345-346); file-backed readers
  * gather the payloads first (the reference mallocs + freads per entry, :336-344). */
@@ -287,9 +327,9 @@ static int read_batch(zpack_reader* reader, zpack_file_entry* const* entries, zp
 {
     if (count == 0) return ZPACK_OK;
     if (!reader->file && !reader->buffer) return ZPACK_ERROR_ARCHIVE_NOT_LOADED;
-    zpk_codec* codec = zi_pick_codec(dctx, &reader->zstd_dctx);
-    if (!codec) return ZPACK_ERROR_NOT_AVAILABLE;            /* no HIP device: there is no CPU fallback */
-    if (!dctx && !reader->zstd_dctx) reader->zstd_dctx = NULL; /* the default codec is shared, not owned */
+    /* the caller's context, else this reader's own, created on first use (lib/zpack_read.c:17-31) and freed by zpack_close_reader */
+    zi_ctx* ctx = zi_pick_ctx(dctx, &reader->zstd_dctx);
+    if (!ctx) return ZPACK_ERROR_NOT_AVAILABLE;              /* no HIP device: there is no CPU fallback */
 
     zpk_decode_desc* desc = (zpk_decode_desc*)calloc((size_t)count, sizeof(*desc));
     zpk_decode_result* res = (zpk_decode_result*)calloc((size_t)count, sizeof(*res));
@@ -326,8 +366,23 @@ static int read_batch(zpack_reader* reader, zpack_file_entry* const* entries, zp
         for (zpack_u64 i = 0; i < count; i++) fill_desc(&desc[i], entries[i], entries[i]->offset, max_sizes[i]);
     }
     if (rc == ZPACK_OK) {
-        int crc = zpk_codec_decode_batch_host(codec, image, image_size, desc, count, buffers, res);
-        if (crc != ZPK_OK) rc = ZPACK_ERROR_NOT_AVAILABLE;
+        read_job job = { ctx, image, image_size, desc, buffers, res, {0}, {0} };
+        int parts = ctx->n;
+        if ((zpack_u64)parts > count) parts = (int)count;
+        if (parts > 1) {
+            /* static shard: contiguous ranges of the batch balanced by comp + uncomp bytes, one host thread
+             * and one codec per device, nothing exchanged; results land in their own slices of res[] */
+            zpack_u64* w = (zpack_u64*)malloc(sizeof(zpack_u64) * (size_t)count);
+            if (!w) parts = 1;
+            else {
+                for (zpack_u64 i = 0; i < count; i++) w[i] = entries[i]->comp_size + entries[i]->uncomp_size;
+                zi_split(w, count, parts, job.cut);
+                free(w);
+            }
+        }
+        if (parts <= 1) { job.cut[0] = 0; job.cut[1] = count; parts = 1; }
+        zi_parallel(parts, read_part, &job);
+        for (int k = 0; k < parts; k++) if (job.rc[k] != ZPK_OK) rc = ZPACK_ERROR_NOT_AVAILABLE;
     }
     if (rc == ZPACK_OK)
         for (zpack_u64 i = 0; i < count; i++) {
@@ -388,9 +443,10 @@ int zpack_read_file_stream(zpack_reader* reader, zpack_file_entry* entry, zpack_
     if (!stream->next_out || !stream->avail_out) return ZPACK_ERROR_STREAM_INVALID;
     zi_stream_state* st = (zi_stream_state*)stream->xxh3_state;
     if (!st) return ZPACK_ERROR_STREAM_INVALID;
-    zpk_codec* codec = zi_pick_codec(dctx, &reader->zstd_dctx);
-    if (!codec) return ZPACK_ERROR_NOT_AVAILABLE;
-    if (!st->d && zpk_dstream_create(codec, &st->d) != ZPK_OK) return ZPACK_ERROR_MALLOC_FAILED;
+    zi_ctx* ctx = zi_pick_ctx(dctx, &reader->zstd_dctx);
+    if (!ctx) return ZPACK_ERROR_NOT_AVAILABLE;
+    if (!st->d && zpk_dstream_create(ctx->dev[0], &st->d) != ZPK_OK) return ZPACK_ERROR_MALLOC_FAILED;
+    zpk_dstream_bind(st->d, ctx->dev[0]);                     /* a stream outlives readers: it decodes with THIS call's context */
     if (stream->total_in == 0 && stream->read_back == 0) { zpk_dstream_reset(st->d); st->d_active = 1; }
 
     zpack_u8* src = stream->next_in;
@@ -455,19 +511,14 @@ int zpack_init_reader_memory_shared(zpack_reader* reader, zpack_u8* buffer, size
 
 void zpack_reset_reader_dctx(zpack_reader* reader)
 {
-    if (reader->zstd_dctx) zpk_codec_reset((zpk_codec*)reader->zstd_dctx);
+    zi_ctx_reset((zi_ctx*)reader->zstd_dctx);                   /* lib/zpack_read.c:679-690: after an abandoned stream / error */
 }
 
 void zpack_close_reader(zpack_reader* reader)
 {
     if (reader->file) fclose(reader->file);
     if (!reader->buffer_shared) free(reader->buffer);
-    if (reader->file_entries) {
-        if (!reader->lz4f_dctx)                                /* names in one arena (reader_load_entries) or one malloc each */
-            for (zpack_u64 i = 0; i < reader->file_count; i++) free(reader->file_entries[i].filename);
-        free(reader->file_entries);
-    }
-    free(reader->lz4f_dctx);
-    if (reader->zstd_dctx) zpk_codec_destroy((zpk_codec*)reader->zstd_dctx);
+    reader_drop_table(reader);                                 /* names in one arena (reader_load_entries) or one malloc each */
+    zi_ctx_destroy((zi_ctx*)reader->zstd_dctx);
     memset(reader, 0, sizeof(*reader));
 }

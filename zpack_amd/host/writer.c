@@ -150,15 +150,27 @@ int zpack_write_eocdr(zpack_writer* writer) { return zpack_write_eocdr_ex(writer
 
 /* ------------------------------------------------------------------ the hot path: compress + hash */
 
+typedef struct {
+    zi_ctx* ctx; const zpack_u8* const* srcs; const zpk_encode_desc* desc; zpack_u8* const* dsts; zpk_encode_result* res;
+    zpack_u64 cut[ZI_MAX_DEVICES + 1]; int rc[ZI_MAX_DEVICES];
+} write_job;
+
+static void write_part(void* arg, int k)
+{
+    write_job* j = (write_job*)arg;
+    const zpack_u64 lo = j->cut[k], n = j->cut[k + 1] - lo;
+    j->rc[k] = n ? zpk_codec_encode_batch_host(j->ctx->dev[k], j->srcs + lo, j->desc + lo, n, j->dsts + lo, j->res + lo) : ZPK_OK;
+}
+
 int zpack_write_files(zpack_writer* writer, zpack_file* files, zpack_u64 file_count)
 {
     if (file_count == 0) return ZPACK_OK;
     if (!writer->file && !writer->buffer) return ZPACK_ERROR_WRITER_NOT_OPENED;
-    /* contexts: a per-file cctx is honoured when every file names the same one, else the default codec */
+    /* contexts: a per-file cctx is honoured when every file names the same one, else the writer's own */
     void* explicit_ctx = files[0].cctx;
     for (zpack_u64 i = 1; i < file_count; i++) if (files[i].cctx != explicit_ctx) explicit_ctx = NULL;
-    zpk_codec* codec = zi_pick_codec(explicit_ctx, &writer->zstd_cctx);
-    if (!codec) return ZPACK_ERROR_NOT_AVAILABLE;            /* no HIP device: there is no CPU fallback */
+    zi_ctx* ctx = zi_pick_ctx(explicit_ctx, &writer->zstd_cctx);     /* lib/zpack_write.c:20-34: the writer's own, created on first use */
+    if (!ctx) return ZPACK_ERROR_NOT_AVAILABLE;              /* no HIP device: there is no CPU fallback */
 
     zpk_encode_desc* desc = (zpk_encode_desc*)calloc((size_t)file_count, sizeof(*desc));
     zpk_encode_result* res = (zpk_encode_result*)calloc((size_t)file_count, sizeof(*res));
@@ -184,7 +196,17 @@ int zpack_write_files(zpack_writer* writer, zpack_file* files, zpack_u64 file_co
     if (rc == ZPACK_OK) {
         zpack_u64 pos = 0;
         for (zpack_u64 i = 0; i < file_count; i++) { dsts[i] = scratch + pos; pos += desc[i].dst_capacity + 16; }
-        if (zpk_codec_encode_batch_host(codec, srcs, desc, file_count, dsts, res) != ZPK_OK) rc = ZPACK_ERROR_NOT_AVAILABLE;
+        write_job job = { ctx, srcs, desc, dsts, res, {0}, {0} };
+        int parts = ctx->n;
+        if ((zpack_u64)parts > file_count) parts = (int)file_count;
+        if (parts > 1) {           /* static shard by source bytes: one host thread + one codec per device */
+            zpack_u64* w = (zpack_u64*)malloc(sizeof(zpack_u64) * (size_t)file_count);
+            if (!w) parts = 1;
+            else { for (zpack_u64 i = 0; i < file_count; i++) w[i] = files[i].size; zi_split(w, file_count, parts, job.cut); free(w); }
+        }
+        if (parts <= 1) { job.cut[0] = 0; job.cut[1] = file_count; parts = 1; }
+        zi_parallel(parts, write_part, &job);
+        for (int k = 0; k < parts; k++) if (job.rc[k] != ZPK_OK) rc = ZPACK_ERROR_NOT_AVAILABLE;
     }
     /* append in order; the first failing file stops the call like the reference loop does (:299-303) */
     for (zpack_u64 i = 0; i < file_count && rc == ZPACK_OK; i++) {
@@ -247,9 +269,10 @@ int zpack_write_file_stream(zpack_writer* writer, zpack_compress_options* option
     if (m != ZPACK_COMPRESSION_NONE && m != ZPACK_COMPRESSION_ZSTD && m != ZPACK_COMPRESSION_LZ4) return ZPACK_ERROR_COMP_METHOD_INVALID;
     zi_stream_state* st = (zi_stream_state*)stream->xxh3_state;
     if (!st) return ZPACK_ERROR_STREAM_INVALID;
-    zpk_codec* codec = zi_pick_codec(cctx, &writer->zstd_cctx);
-    if (!codec) return ZPACK_ERROR_NOT_AVAILABLE;
-    if (!st->c && zpk_cstream_create(codec, &st->c) != ZPK_OK) return ZPACK_ERROR_MALLOC_FAILED;
+    zi_ctx* ctx = zi_pick_ctx(cctx, &writer->zstd_cctx);
+    if (!ctx) return ZPACK_ERROR_NOT_AVAILABLE;
+    if (!st->c && zpk_cstream_create(ctx->dev[0], &st->c) != ZPK_OK) return ZPACK_ERROR_MALLOC_FAILED;
+    zpk_cstream_bind(st->c, ctx->dev[0]);
     if (stream->total_in == 0) { zpk_cstream_reset(st->c); st->c_active = 1; }
     int rc = zpk_cstream_update(st->c, stream->next_in, stream->avail_in);
     if (rc) return rc;
@@ -267,9 +290,10 @@ int zpack_write_file_stream_end(zpack_writer* writer, char* filename, zpack_comp
     if (!writer->file && !writer->buffer) return ZPACK_ERROR_WRITER_NOT_OPENED;
     zi_stream_state* st = (zi_stream_state*)stream->xxh3_state;
     if (!st) return ZPACK_ERROR_STREAM_INVALID;
-    zpk_codec* codec = zi_pick_codec(cctx, &writer->zstd_cctx);
-    if (!codec) return ZPACK_ERROR_NOT_AVAILABLE;
-    if (!st->c && zpk_cstream_create(codec, &st->c) != ZPK_OK) return ZPACK_ERROR_MALLOC_FAILED;   /* an empty entry: end without update */
+    zi_ctx* ctx = zi_pick_ctx(cctx, &writer->zstd_cctx);
+    if (!ctx) return ZPACK_ERROR_NOT_AVAILABLE;
+    if (!st->c && zpk_cstream_create(ctx->dev[0], &st->c) != ZPK_OK) return ZPACK_ERROR_MALLOC_FAILED;   /* an empty entry: end without update */
+    zpk_cstream_bind(st->c, ctx->dev[0]);
     if (stream->total_in == 0 && !st->c_active) zpk_cstream_reset(st->c);
     uint64_t csize = 0, usize = 0, hash = 0;
     int rc = zpk_cstream_finish(st->c, (uint32_t)m, options->level, &csize, &usize, &hash);
@@ -312,6 +336,6 @@ void zpack_close_writer(zpack_writer* writer)
         for (zpack_u64 i = 0; i < writer->file_count; i++) free(writer->file_entries[i].filename);
         free(writer->file_entries);
     }
-    if (writer->zstd_cctx) zpk_codec_destroy((zpk_codec*)writer->zstd_cctx);
+    zi_ctx_destroy((zi_ctx*)writer->zstd_cctx);
     memset(writer, 0, sizeof(*writer));
 }
