@@ -53,7 +53,7 @@ def Z():
 def _mixed_files(n, seed, lo=1, hi=90000):
     rng = np.random.default_rng(seed)
     sizes = [int(x) for x in rng.integers(lo, hi, n)]
-    return [("m%04d" % i, dg.fill(i % 4, seed, i, s).tobytes()) for i, s in enumerate(sizes)]
+    return [("s%d_m%04d" % (seed, i), dg.fill(i % 4, seed, i, s).tobytes()) for i, s in enumerate(sizes)]
 
 
 def _archive(Z, files, method, level):
