@@ -187,7 +187,7 @@ def main():
     # ---- dominant-kernel time, HIP events on the launch stream ----
     # (Zstandard runs as a pipeline: k_zstd_fse pre-decodes the sequence streams, k_zstd_exec + k_zstd do the rest;
     # its figure is the sum of the stages, bracketed on the stream one after the other)
-    kids = dict(lz4=[zpack_amd.K_LZ4], zstd=[zpack_amd.K_ZSTD_FSE, zpack_amd.K_ZSTD], stored=[zpack_amd.K_STORED])[w["kernel"]]
+    kids = dict(lz4=[zpack_amd.K_LZ4_SCAN, zpack_amd.K_LZ4], zstd=[zpack_amd.K_ZSTD_FSE, zpack_amd.K_ZSTD], stored=[zpack_amd.K_STORED])[w["kernel"]]
     codec.set_profiling(True)
     kms, stage_ms = [], None
     for _ in range(max(3, min(args.steps, 10))):

@@ -182,6 +182,31 @@ struct Xxh3Wave {
     }
 };
 
+// The same state in 4 registers instead of 12: the per-lane secret words are re-read from the constant table for every block (for
+// kernels whose occupancy is worth more than four cached loads per KiB)
+struct Xxh3Lite {
+    u64 a0, a1;
+    __device__ __forceinline__ void init(int lane)
+    {
+        Xxh3Wave w; w.init(lane); a0 = w.a0; a1 = w.a1;
+    }
+    __device__ __forceinline__ void block(u128 d, int lane)
+    {
+        const int q = lane & 3, s = lane >> 2;
+        u64 c0, c1;
+        Xxh3Wave::slot(d.lo, d.hi, sec64(8 * s + 16 * q), sec64(8 * s + 16 * q + 8), c0, c1);
+        Xxh3Wave::reduce16(c0, c1);
+        a0 += c0; a1 += c1;
+        a0 = ((a0 ^ (a0 >> 47)) ^ sec64(128 + 16 * q)) * ZPK_P32_1;
+        a1 = ((a1 ^ (a1 >> 47)) ^ sec64(128 + 16 * q + 8)) * ZPK_P32_1;
+    }
+    __device__ __forceinline__ u64 finish(const u8* p, u32 nstripes, const u8* end, u64 total_len, int lane)
+    {
+        Xxh3Wave w; w.init(lane); w.a0 = a0; w.a1 = a1;
+        return w.finish(p, nstripes, end, total_len, lane);
+    }
+};
+
 // XXH3_64bits(p, len) computed by one full wave (all 64 lanes must call; result uniform).
 // `p` may have any alignment.
 __device__ __forceinline__ u64 xxh3_64_wave(const u8* p, u64 len, int lane)
