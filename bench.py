@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--mix", type=int, default=-1, help="-1 = 70/20/5/5 class mix, 0..3 = single class")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lz4-ring", action="store_true", help="LZ4 entries through the scan + LDS-ring executor first (zpk_codec_set_option ZPK_OPT_LZ4_RING)")
     ap.add_argument("--skip-hash", action="store_true", help="diagnostic only: decode without the XXH3 verify (the line says so)")
     args = ap.parse_args()
 
@@ -123,6 +124,8 @@ def main():
     n = batch.n
 
     codec = zpack_amd.Codec(local_rank)
+    if args.lz4_ring:
+        codec.set_option(zpack_amd.OPT_LZ4_RING, 1)
     src = torch.from_numpy(batch.archive).to(dev)
     dst = torch.empty(dst_bytes, dtype=torch.uint8, device=dev)
     ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)

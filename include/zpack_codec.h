@@ -109,6 +109,11 @@ void        zpk_codec_destroy(zpk_codec* c);
 void        zpk_codec_reset(zpk_codec* c);                  /* after an abandoned stream / error */
 const char* zpk_codec_last_error(const zpk_codec* c);
 int         zpk_codec_device(const zpk_codec* c);
+/* options.  ZPK_OPT_LZ4_RING (default 0): put the token scan + LDS-ring executor (lz4_ring.h) in front of the general LZ4 decoder.  Same
+ * results by contract (the general decoder finishes whatever the ring path declines); on MI355X it is not yet the faster of the two
+ * on the 64 KiB batch, so it is opt-in. */
+enum { ZPK_OPT_LZ4_RING = 1 };
+int         zpk_codec_set_option(zpk_codec* c, int option, int value);
 
 /* ---- batch decode + verify ----------------------------------------------------------------
  * Device-resident form: every pointer is a DEVICE pointer on the codec's device; work is enqueued on
@@ -163,7 +168,8 @@ enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2 /* k_lz4_exec + k_lz4
        ZPK_K_LZ4_SCAN = 6, ZPK_K_COUNT = 7 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
 /* zpk_codec_decode_stats2: out[0] = LZ4 entries finished by the ring path, out[1] = left to the general decoder, out[2..10] = the
- * leftovers by reason (0 not listed by the scan, then LX_E_* of lz4_ring.h) */
+ * leftovers by reason (0 not a plain frame, then LX_E_* of lz4_ring.h), out[11] a unit could not be listed, out[12] a seam did not
+ * join, out[13] scan units */
 int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16]);
 /* counters of the most recent decode batch (synchronises): out[0..2] = entries on the stored / zstd / lz4 work
  * lists, out[3] = Zstandard entries finished on pre-decoded sequences (two-stage path), out[4] = by the fused decoder,

@@ -17,6 +17,7 @@ ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
 METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
 DF_GENERAL = 2
+OPT_LZ4_RING = 1
 K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_LZ4_SCAN = 0, 1, 2, 3, 4, 5, 6
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
@@ -131,6 +132,10 @@ class Codec:
         self._chk(self.L.zpk_codec_hash_batch_device(self.h, src.data_ptr(), offsets_dev.data_ptr(), sizes_dev.data_ptr(),
                                                      n, hashes_dev.data_ptr(), st), "zpk_codec_hash_batch_device")
 
+    def set_option(self, option, value):
+        self.L.zpk_codec_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._chk(self.L.zpk_codec_set_option(self.h, option, value), "set_option")
+
     def set_profiling(self, on):
         self._chk(self.L.zpk_codec_set_profiling(self.h, 1 if on else 0), "set_profiling")
 
@@ -147,7 +152,7 @@ class Codec:
         self.L.zpk_codec_decode_stats2.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         self._chk(self.L.zpk_codec_decode_stats2(self.h, b), "decode_stats2")
         return dict(stored=a[0], zstd=a[1], lz4=a[2], zstd_two_stage=a[3], zstd_fused=a[4], fse_watchdog=a[5], fse_budget=a[6],
-                    lz4_ring=b[0], lz4_general=b[1], lz4_general_why=[b[2 + i] for i in range(9)],
+                    lz4_ring=b[0], lz4_general=b[1], lz4_general_why=[b[2 + i] for i in range(11)], lz4_units=b[13],
                     zstd_arena_refused=bool(a[7] >> 31), lz4_lists_refused=bool((a[7] >> 30) & 1))
 
     def debug_fetch(self, what, offset, count, dtype):

@@ -29,18 +29,18 @@
 
 namespace zpk {
 
-// LDS per wave decides how many waves hide each other's latency (the executor is latency-bound): 3 KiB ring + 2 x 1 KiB stage
-// + dump = 5.4 KiB -> 28 waves per CU.
+// LDS per wave: 4 KiB ring + 2 x 1.1 KiB stage = 6.3 KiB -> 25 waves per CU (measured: 20, 28 and 32 waves per CU run the same
+// speed — the executor is bound by vector-ALU issue, not by latency).
 #ifndef LX_MAX_LL
-#define LX_MAX_LL 512u                       // longest literal run / match of a "friendly" entry
+#define LX_MAX_LL 1024u                      // longest literal run / match of a "friendly" entry (the first run of a text is several hundred bytes)
 #endif
 #define LX_MAX_ML LX_MAX_LL
 #ifndef LX_RING
-#define LX_RING 3072u                        // bytes of output kept in LDS: abs positions [rb, rb + LX_RING), rb a multiple of 1 KiB
+#define LX_RING 4096u                        // bytes of output kept in LDS: abs positions [rb, rb + LX_RING), rb a multiple of 1 KiB
 #endif
 #define LX_HIST 1024u                        // a slide keeps at least this much flushed history (>= LX_MAX_ML: a source is all-ring or all-memory)
 #ifndef LX_STAGE
-#define LX_STAGE 1024u                       // compressed span of one batch (>= 1 + 3 + LX_MAX_LL + 2 + 3)
+#define LX_STAGE 1088u                       // compressed span of one batch (>= 1 + 3 + LX_MAX_LL + 2 + 3)
 #endif
 static_assert(LX_STAGE >= LX_MAX_LL + 16u, "one sequence always fits the stage");
 static_assert(LX_RING - LX_HIST - 1023u >= LX_MAX_LL + LX_MAX_ML, "one sequence always fits behind a slide");
@@ -53,22 +53,30 @@ __device__ __forceinline__ u64 lx_region(u64 off) { return ((off * 3) >> 4) << 2
 
 // The scan works in UNITS: a unit is one LX_SEG-byte segment of one compressed block.  k_lz4_frames (one lane per entry) checks the
 // frame header, walks the block headers and appends a unit record per segment; k_lz4_scan (one lane per unit) lists the tokens that
-// START inside its segment.  Segment 0 starts on the true chain (block position 0); every other segment starts its walk LX_RUNIN
-// bytes early at an arbitrary byte — LZ4 token chains re-synchronise within a few dozen bytes — and records nothing before its
-// segment begins.  Nothing trusts that: the executor verifies the whole chain as it uses it (a unit that did not synchronise shows
-// up as a token that does not end where the next one starts, and the entry goes to the general decoder).  One lane per entry
-// (64 KiB = ~5 k serial token steps at ~1.5 waves per SIMD) took 6-8 ms for the C2 batch; units give 8x the lanes and 1/8 the chain.
+// START inside its segment and notes where its chain leaves the segment (the unit's EXIT).  Segment 0 starts on the true chain (block
+// position 0); every other segment starts its walk LX_RUNIN bytes early at an arbitrary byte — LZ4 token chains re-synchronise within
+// a few dozen bytes on text — and records nothing before its segment begins.  k_lz4_seam (one lane per seam) then makes the chain
+// EXACT: from unit j's exit it walks on until it steps on a token that unit j+1 listed; the tokens walked are unit j+1's PATCH and the
+// listed token is where unit j+1's own list becomes valid.  If unit j's tail is true so is its exit, hence the patch, hence unit j+1
+// from the joining token on, hence its tail: by induction from unit 0 the whole chain is the true one whenever every seam joins inside
+// the next segment (else the entry is left to the general decoder; periodic data — the records class — needs 1 KiB and more to join in
+// 1 % of the seams).  And nothing trusts even that: the executor verifies the chain as it uses it.  One lane per block (64 KiB = ~5 k
+// serial token steps at 1.5 waves per SIMD) took 4 ms for the C2 batch; units give 8x the lanes and 1/8 the chain.
 #ifndef LX_SEG
-#define LX_SEG 65536u                       // = the block size: every unit starts on the true chain (see below)
+#define LX_SEG 8192u
 #endif
 #define LX_RUNIN 384u
 #ifndef LXS_WIN
-#define LXS_WIN 256u                         // per-lane window of the compressed stream in LDS
+#define LXS_WIN 256u                         // per-lane window of the compressed stream in LDS (measured: 128 B windows = 17 waves per CU run the
+                                             // scan 45 % SLOWER — the wave-wide refills, one memory round trip each, set the pace, not occupancy)
 #endif
 #define LXS_STRIDE (LXS_WIN + 16u)           // 16-byte aligned slots
 struct alignas(16) Lz4ScanShared { u8 win[64 * LXS_STRIDE + 32]; };
 struct Lz4Unit { u64 blk; u32 bsz_seg; u32 entry; };      // block payload offset in src; bsz | segment index << 20; entry index
 
+// segments of a block of bsz bytes: LX_SEG each, the last one takes a remainder of less than a quarter segment along
+__device__ __forceinline__ u32 lx_nsub(u32 bsz) { const u32 n = (bsz + (LX_SEG * 3) / 4) / LX_SEG; return n ? n : 1u; }
+__device__ __forceinline__ u32 lx_seg_hi(u32 bsz, u32 j) { return j + 1 >= lx_nsub(bsz) ? bsz : (j + 1) * LX_SEG; }
 // sub-list of the segment that starts at source offset `seg_abs`: [u32 count][u16 block-relative token position x count]
 __device__ __forceinline__ u64 lx_sublist(u64 seg_abs) { return lx_region(seg_abs); }
 
@@ -120,7 +128,7 @@ __device__ inline u32 lz4_frames_wave(const u8* src, u64 read_hi, u64 e_off, u64
                     bsz = bh & 0x7FFFFFFFu;
                     if (bsz > 65536u || (u64)(iend - ip) < bsz || (bsz == 0 && !(bh >> 31))) { ok = false; walking = false; }
                     else {
-                        if (!(bh >> 31)) { nu = (bsz + LX_SEG - 1) / LX_SEG; blk = ip; }
+                        if (!(bh >> 31)) { nu = lx_nsub(bsz); blk = ip; }
                         ip += bsz;
                     }
                 }
@@ -148,16 +156,17 @@ __device__ inline u32 lz4_frames_wave(const u8* src, u64 read_hi, u64 e_off, u64
 // limits, list region full): the caller clears the entry's verdict.  All 64 lanes call (lanes without a unit pass bsz = 0).
 __device__ inline bool lz4_scan_units(Lz4ScanShared& sh, const u8* src, u64 read_hi, u64 blk, u32 bsz, u32 seg, u8* tok, int lane)
 {
-    const u32 seg_lo = seg * LX_SEG, seg_hi = seg_lo + LX_SEG < bsz ? seg_lo + LX_SEG : bsz;
+    const u32 seg_lo = seg * LX_SEG, seg_hi = lx_seg_hi(bsz, seg);
     u64 w = lx_sublist(blk + seg_lo);
     const u64 wend = lx_sublist(blk + seg_hi);
-    const u64 cw = w;
-    w += 4;
-    bool ok = bsz != 0 && w <= wend && read_hi >= blk + LXS_WIN;
+    const u64 cw = w;                          // header: [u32 count][u32 exit]; positions follow; [u32 patch count][u32 valid from] end the region
+    w += 8;
+    bool ok = bsz != 0 && w + 8 <= wend && read_hi >= blk + LXS_WIN;
+    u32 exit_pos = bsz;
     const u32 max_wpos = ok ? (read_hi - blk - LXS_WIN > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)(read_hi - blk - LXS_WIN)) : 0u;
     bool live = ok;
     u32 p = seg_lo > LX_RUNIN ? seg_lo - LX_RUNIN : 0u;        // (segment 0, or a run-in that reaches position 0, is the true chain)
-    u32 wpos = 0, n = 0, pend = 0;
+    u32 wpos = 0, n = 0;
     const lds_p8 slot = to_lds_rw(sh.win) + LXS_STRIDE * (u32)lane;
     bool fill = true;
     for (u32 step = 0;; step++) {
@@ -175,56 +184,118 @@ __device__ inline bool lz4_scan_units(Lz4ScanShared& sh, const u8* src, u64 read
             }
             wave_mem_fence();
         }
-        // ---- one token per live lane; the common shapes (at most one extension byte per length) without a branch ----
-        const u32 a = live ? p - wpos : 0u;                                    // < LXS_WIN - 3 after a refill check
+        // ---- one token per live lane.  The common shapes (at most one extension byte per length, everything inside the window and
+        // the block) run straight-line: the loop is executed ~1.3 k times by ~8 k waves, every instruction in it counts ----
+        const u32 a = live ? p - wpos : 0u;                                    // <= LXS_WIN - 4 after the refill check
         const u32 t = lds_ld8((lds_cp8)(slot + a));
         const u32 e1 = lds_ld8((lds_cp8)(slot + a + 1));
-        u32 lit = t >> 4, q = p + 1;
-        const bool lx = lit == 15;
-        lit += lx ? e1 : 0u; q += lx ? 1u : 0u;
-        bool slow = lx && e1 == 255;                                           // 270+ literals: rare
-        const u32 mlc = t & 15;
-        const u32 mo = q + lit;                                                // offset field
+        const bool lx = (t >> 4) == 15;
+        u32 lit = (t >> 4) + (lx ? e1 : 0u);
+        const u32 mo = p + 1 + (lx ? 1u : 0u) + lit;                           // offset field
         const u32 a2 = mo + 2 - wpos;
         const bool far = a2 >= LXS_WIN;                                        // the match-length byte lies beyond the window
         const u32 e2 = lds_ld8((lds_cp8)(slot + (far ? 0u : a2)));
-        slow = slow || (mlc == 15 && (far || e2 == 255));
-        u32 nxt = mo + 2 + (mlc == 15 ? 1u : 0u);
-        u32 ml = mlc + (mlc == 15 ? e2 : 0u);
+        const u32 mlc = t & 15;
+        const bool mx = mlc == 15;
+        u32 nxt = mo + 2 + (mx ? 1u : 0u);
         bool last = mo == bsz;                                                 // literals run to the end of the block: the last sequence
-        bool bad = false;
-        if (live && slow) {                                                    // general form, bytes straight from memory
-            const u8* b = src + blk;
-            q = p + 1; lit = t >> 4;
-            if (lit == 15) { u32 x; do { if (q >= bsz) { bad = true; break; } x = ld8(b + q); q++; lit += x; } while (x == 255 && lit <= LX_MAX_LL); }
-            if (!bad && lit > bsz - q) bad = true;
-            if (!bad) {
-                const u32 m2 = q + lit;
-                last = m2 == bsz;
-                nxt = m2 + 2; ml = mlc;
-                if (!last && mlc == 15) { u32 x; do { if (nxt >= bsz) { bad = true; break; } x = ld8(b + nxt); nxt++; ml += x; } while (x == 255 && ml <= LX_MAX_ML); }
+        bool reject = mo > bsz || (!last && (bsz - mo < 2 || nxt >= bsz));
+        const bool special = (lx && e1 == 255) || (mx && !last && (far || e2 == 255)) || reject;
+        if (__ballot(live && special) != 0) {                                  // rare: long extension chains, malformed tokens, run-in misses
+            if (live && special) {
+                const u8* b = src + blk;
+                bool bad = false;
+                u32 q = p + 1, ml = mlc;
+                lit = t >> 4;
+                if (lit == 15) { u32 x; do { if (q >= bsz) { bad = true; break; } x = ld8(b + q); q++; lit += x; } while (x == 255 && lit <= LX_MAX_LL); }
+                if (!bad && (lit > LX_MAX_LL || lit > bsz - q)) bad = true;
+                if (!bad) {
+                    const u32 m2 = q + lit;
+                    last = m2 == bsz;
+                    nxt = m2 + 2;
+                    if (!last) {
+                        if (bsz - m2 < 2) bad = true;
+                        else if (mx) { u32 x; do { if (nxt >= bsz) { bad = true; break; } x = ld8(b + nxt); nxt++; ml += x; } while (x == 255 && ml <= LX_MAX_ML); }
+                        if (!bad && (ml + 4 > LX_MAX_ML || nxt >= bsz)) bad = true;
+                    }
+                }
+                reject = bad;
             }
         }
-        if (live) {
-            const bool reject = bad || lit > LX_MAX_LL || mo > bsz || (!last && (bsz - mo < 2 || ml + 4 > LX_MAX_ML || nxt >= bsz));
-            if (reject && p < seg_lo) { p++; fill = p - wpos > LXS_WIN - 4u; }     // still in the run-in: not a token after all, try the next byte
-            else if (reject) { ok = false; live = false; }
-            else {
-                if (p >= seg_lo) {                                             // the token starts inside this segment: list it
-                    if (n & 1) { if (w + 4 > wend) { ok = false; live = false; } else { st32(tok + w, pend | (p << 16)); w += 4; } } else pend = p;
-                    n++;
-                }
-                if (last) live = false;
-                else { p = nxt; if (p >= seg_hi) live = false; }
-                fill = p - wpos > LXS_WIN - 4u;
-            }
+        {   // the step's outcome, by selects (one exec-masked store is the only divergent piece)
+            const bool miss = live && reject && p < seg_lo;                    // still in the run-in: not a token after all, try the next byte
+            const bool fail = live && reject && p >= seg_lo;
+            const bool good = live && !reject;
+            const bool rec = good && p >= seg_lo;                              // the token starts inside this segment: list it
+            const bool full = rec && w + 10 > wend;
+            if (rec && !full) st16(tok + w, (u16)p);
+            w += rec && !full ? 2u : 0u;
+            n += rec && !full ? 1u : 0u;
+            ok = ok && !fail && !full;
+            const bool leave = good && !last && nxt >= seg_hi;                 // the chain leaves the segment: the unit's exit
+            exit_pos = leave ? nxt : exit_pos;                                 // (a chain that ENDS inside the unit keeps exit = bsz)
+            p = miss ? p + 1 : (good && !last ? nxt : p);
+            live = live && !fail && !full && !(good && last) && !leave;
+            fill = p - wpos > LXS_WIN - 4u;
         }
     }
     if (ok) {
-        if (n & 1) { if (w + 4 > wend) ok = false; else st32(tok + w, pend); }
-        if (ok) st32(tok + cw, n);
+        { st32(tok + cw, n); st32(tok + cw + 4, exit_pos); st32(tok + wend - 8, 0u); st32(tok + wend - 4, 0u); }
     }
     return ok || bsz == 0;
+}
+
+// One lane per seam (unit j -> unit j + 1 of the same block): see the comment above.  Returns false when the seam does not join.
+__device__ inline bool lz4_seam(const u8* src, u64 blk, u32 bsz, u32 seg, u8* tok)
+{
+    const u32 lo1 = (seg + 1) * LX_SEG;
+    if (bsz == 0 || seg + 1 >= lx_nsub(bsz)) return true;                        // the block's last unit: no seam behind it
+    const u32 hi1 = lx_seg_hi(bsz, seg + 1);
+    const u64 r0 = lx_sublist(blk + seg * LX_SEG), r1 = lx_sublist(blk + lo1), r1e = lx_sublist(blk + hi1);
+    const u32 X = ld32(tok + r0 + 4);
+    const u32 c1 = ld32(tok + r1);
+    const u8* L = tok + r1 + 8;
+    u32 pc = 0, v = 0;
+    if (X >= bsz) v = c1;                                                        // the chain ended before this seam: nothing of unit j + 1 is real
+    else if (c1 != 0 && (u32)ld16(L) == X) v = 0;                                 // the common case: unit j + 1 was on the chain from its first token
+    else {
+        if (X < lo1) return false;
+        const u8* b = src + blk;
+        const u64 floor_ = r1 + 8 + 2ull * ((c1 + 1) & ~1u);
+        u64 pw = 0;
+        // two passes over the same short walk: count the patch, then write it in ascending order just below its header
+        for (int pass = 0; pass < 2; pass++) {
+            u32 p = X, idx = 0, k = 0;
+            for (;;) {
+                while (idx < c1 && (u32)ld16(L + 2ull * idx) < p) idx++;
+                if (idx < c1 && (u32)ld16(L + 2ull * idx) == p) { v = idx; break; }   // joined unit j + 1's own chain
+                if (p >= hi1) return false;                                          // left the segment without joining: give the entry up
+                if (pass) st16(tok + pw + 2ull * k, (u16)p);
+                k++;
+                // next token (bytes straight from memory: seams that need a patch are few and their walks short)
+                const u32 t = ld8(b + p);
+                u32 q = p + 1, lit = t >> 4;
+                if (lit == 15) { u32 x; do { if (q >= bsz) return false; x = ld8(b + q); q++; lit += x; } while (x == 255 && lit <= LX_MAX_LL); }
+                if (lit > LX_MAX_LL || lit > bsz - q) return false;
+                q += lit;
+                if (q == bsz) { v = c1; break; }                                     // the block's last sequence was in the patch
+                if (bsz - q < 2) return false;
+                q += 2;
+                u32 ml = t & 15;
+                if (ml == 15) { u32 x; do { if (q >= bsz) return false; x = ld8(b + q); q++; ml += x; } while (x == 255 && ml <= LX_MAX_ML); }
+                if (ml + 4 > LX_MAX_ML || q >= bsz) return false;
+                p = q;
+            }
+            if (!pass) {
+                pc = k;
+                const u64 need = 2ull * ((pc + 1) & ~1u);
+                if (r1e - 8 < floor_ + need) return false;                           // no room between unit j + 1's list and its patch header
+                pw = r1e - 8 - need;
+            }
+        }
+    }
+    st32(tok + r1e - 8, pc); st32(tok + r1e - 4, v);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ executor
@@ -371,7 +442,7 @@ __device__ inline int lx_block(Lz4ExecShared& sh, LxOut& O, const u8* blk, u32 C
     auto load_pos = [&](u32 b, u32& p, u32& n) {
         const u32 i = b + (u32)lane;
         p = 0; n = 0;
-        if (i < nseq) { p = (u32)ld16(lst + 2ull * i); n = i + 1 < nseq ? (u32)ld16(lst + 2ull * (i + 1)) : end_pos; }
+        if (i < nseq) { const u32 pn = ld32(lst + 2ull * i); p = pn & 0xFFFFu; n = i + 1 < nseq ? pn >> 16 : end_pos; }   // (lists are padded: 2 bytes past the last position are readable)
     };
     // the batch that starts at sequence b with positions (p, n): how many sequences the stage holds, and their compressed span.
     // false: the list is not a strictly increasing chain inside the block (not a list this path wrote)
@@ -388,6 +459,7 @@ __device__ inline int lx_block(Lz4ExecShared& sh, LxOut& O, const u8* blk, u32 C
         return true;
     };
     u32 b0 = 0, P, Nx, Pn = 0, Nxn = 0;
+    u32 c_cnt = 0, c_pf = 0, c_span = 0;   // the current batch's plan when it was already made for the prefetch (c_cnt != 0)
     int buf = 0;
     bool staged = false;          // stage[buf] is receiving (LDS-DMA) the span of the batch at b0
     bool have_next = false;       // (Pn, Nxn) are the positions of the batch at b0 + 64
@@ -395,7 +467,8 @@ __device__ inline int lx_block(Lz4ExecShared& sh, LxOut& O, const u8* blk, u32 C
     while (b0 < nseq) {
         u32 cnt, p_first, span;
         LXT(10);
-        if (!plan(b0, P, Nx, cnt, p_first, span)) return LX_E_LIST;
+        if (c_cnt) { cnt = c_cnt; p_first = c_pf; span = c_span; }
+        else if (!plan(b0, P, Nx, cnt, p_first, span)) return LX_E_LIST;
         LXT(11);
         if (O.rb + LX_RING - O.wp < LX_MAX_LL + LX_MAX_ML + 1) lx_slide(O, lane);      // room for any ordinary batch up front
         LXT(9);
@@ -418,11 +491,12 @@ __device__ inline int lx_block(Lz4ExecShared& sh, LxOut& O, const u8* blk, u32 C
         // ---- prefetch: batch b0 + 64's span into the other stage buffer, batch b0 + 128's positions into registers ----
         bool next_staged = false;
         u32 Pf = 0, Nxf = 0;
+        u32 cn = 0, pfn = 0, spn = 0;
         const bool rhythm = cnt == 64u;
         if (rhythm && b0 + 64u < nseq) {
             if (have_next) {
-                u32 cn, pfn, spn;
-                if (plan(b0 + 64u, Pn, Nxn, cn, pfn, spn) && blk + pfn + spn + 8u + 16u <= read_hi) {
+                if (!plan(b0 + 64u, Pn, Nxn, cn, pfn, spn)) return LX_E_LIST;
+                if (blk + pfn + spn + 8u + 16u <= read_hi) {
                     const u8* g = blk + pfn + 16u * (u32)lane;
                     ZPK_LDS u8* const d0 = (ZPK_LDS u8*)sh.stage[buf ^ 1];
                     if (16u * (u32)lane < spn + 8u) __builtin_amdgcn_global_load_lds((const ZPK_GLOBAL u32*)g, (ZPK_LDS u32*)d0, 16, 0, 0);
@@ -528,12 +602,6 @@ __device__ inline int lx_block(Lz4ExecShared& sh, LxOut& O, const u8* blk, u32 C
         const bool early = has_match && !overlap && srel + (i64)need_len <= 0;
         const lds_p8 ring = O.ring;
         LXT(4);
-#ifdef LX_ABL_DECODEONLY
-        O.wp += total; lx_flush_blocks(O, lane); b0 += cnt;
-        if (cnt == planned && rhythm && b0 < nseq) { P = Pn; Nx = Nxn; Pn = Pf; Nxn = Nxf; staged = have_next && next_staged; buf ^= 1; have_next = b0 + 64u < nseq; }
-        else if (b0 < nseq) { if (next_staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); load_pos(b0, P, Nx); have_next = false; staged = false; }
-        continue;
-#endif
         // ---- literals: stage -> ring ----
 #ifndef LX_ABL_NOLIT
         {
@@ -618,11 +686,12 @@ __device__ inline int lx_block(Lz4ExecShared& sh, LxOut& O, const u8* blk, u32 C
         if (cnt == planned && rhythm && b0 < nseq) {                          // in rhythm: what was "next" is current now
             P = Pn; Nx = Nxn; Pn = Pf; Nxn = Nxf;
             staged = have_next && next_staged;
+            c_cnt = have_next ? cn : 0u; c_pf = pfn; c_span = spn;
             buf ^= 1;
             have_next = b0 + 64u < nseq;
         } else if (b0 < nseq) {
             if (next_staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // let the orphaned DMA land before its buffer is reused
-            load_pos(b0, P, Nx); have_next = false; staged = false;
+            load_pos(b0, P, Nx); have_next = false; staged = false; c_cnt = 0;
         }
     }
     return LX_OK;
@@ -679,32 +748,40 @@ __device__ inline LxResult lz4f_exec_wave(Lz4ExecShared& sh, const u8* src, cons
         if (bh >> 31) rc = lx_append_raw(O, ip, bsz, read_hi, dst_cap, lane);
         else {
             const u64 blk_abs = (u64)(ip - src);
-            const u32 nsub = (bsz + LX_SEG - 1) / LX_SEG;
+            const u32 nsub = lx_nsub(bsz);
             u32 hist_lo = indep ? O.wp : 0u;
             if (O.wp - hist_lo > 65536u) hist_lo = O.wp - 65536u;
             const u32 block_out = O.wp;
             rc = LX_OK;
+            // The block's chain = for every unit j: its PATCH (tokens between unit j - 1's exit and the token where unit j's own list
+            // joins the chain; usually none), then its list from that token on.  part k = 2j: patch of unit j, k = 2j + 1: its list.
+            auto part = [&](u32 k, const u8*& ptr, u32& cnt) -> bool {
+                const u32 j = k >> 1, seg_lo = j * LX_SEG, seg_hi = lx_seg_hi(bsz, j);
+                const u64 r0 = lx_sublist(blk_abs + seg_lo), r1 = lx_sublist(blk_abs + seg_hi);
+                if (r0 + 16 > r1) return false;
+                const u32 c = uld32(tok + r0), pc = uld32(tok + r1 - 8), v = uld32(tok + r1 - 4);
+                const u64 lend = r0 + 8 + 2ull * ((c + 1) & ~1u), pbeg = r1 - 8 - 2ull * ((pc + 1) & ~1u);
+                if (c > 21846u || pc > 21846u || v > c || lend > pbeg || pbeg < r0 + 8) return false;     // everything stays inside the unit's own region
+                if (k & 1) { ptr = tok + r0 + 8 + 2ull * v; cnt = c - v; } else { ptr = tok + pbeg; cnt = pc; }
+                return true;
+            };
             bool first = true;
-            for (u32 j = 0; j < nsub && rc == LX_OK; j++) {
-                const u32 seg_lo = j * LX_SEG, seg_hi = seg_lo + LX_SEG < bsz ? seg_lo + LX_SEG : bsz;
-                const u64 wj = lx_sublist(blk_abs + seg_lo), wj_end = lx_sublist(blk_abs + seg_hi);
-                if (wj + 4 > wj_end) { rc = LX_E_LIST; break; }
-                const u32 nseq = uld32(tok + wj);
+            for (u32 k = 0; k < 2 * nsub && rc == LX_OK; k++) {
+                const u8* lst; u32 nseq;
+                if (!part(k, lst, nseq)) { rc = LX_E_LIST; break; }
                 if (nseq == 0) continue;
-                if (nseq > 21846u || wj + 4 + 2ull * nseq > wj_end) { rc = LX_E_LIST; break; }      // the list stays inside its own region
-                // where this sub-list's last token must end: the first token of the next sub-list that has one, else the end of the block
+                // where this part's last token must end: the first token of the next part that has one, else the end of the block
                 u32 end_pos = bsz;
                 bool final = true;
-                for (u32 k = j + 1; k < nsub; k++) {
-                    const u32 k_lo = k * LX_SEG, k_hi = k_lo + LX_SEG < bsz ? k_lo + LX_SEG : bsz;
-                    const u64 wk = lx_sublist(blk_abs + k_lo);
-                    if (wk + 6 > lx_sublist(blk_abs + k_hi)) { rc = LX_E_LIST; break; }
-                    if (uld32(tok + wk) != 0) { end_pos = uld16(tok + wk + 4); final = false; break; }
+                for (u32 k2 = k + 1; k2 < 2 * nsub; k2++) {
+                    const u8* l2; u32 n2;
+                    if (!part(k2, l2, n2)) { rc = LX_E_LIST; break; }
+                    if (n2 != 0) { end_pos = uld16(l2); final = false; break; }
                 }
                 if (rc != LX_OK) break;
-                if (first && uld16(tok + wj + 4) != 0) { rc = LX_E_LIST; break; }                    // a block's chain starts at its first byte
+                if (first && uld16(lst) != 0) { rc = LX_E_LIST; break; }                             // a block's chain starts at its first byte
                 first = false;
-                rc = lx_block(sh, O, ip, bsz, read_hi, tok + wj + 4, nseq, seg_lo, end_pos, final, block_out, hist_lo, dst_cap, lane);
+                rc = lx_block(sh, O, ip, bsz, read_hi, lst, nseq, (k >> 1) * LX_SEG, end_pos, final, block_out, hist_lo, dst_cap, lane);
             }
             if (rc == LX_OK && first) rc = LX_E_LIST;                                                // no token at all
         }

@@ -23,6 +23,9 @@
 #include "xxh3_device.h"
 #include "lz4_wave.h"
 #include "lz4_ring.h"
+#ifndef LX_WAVES_PER_SIMD
+#define LX_WAVES_PER_SIMD 6
+#endif
 #include "zstd_wg.h"
 #include "zstd_fse4.h"
 
@@ -226,11 +229,22 @@ __global__ __launch_bounds__(64) void k_lz4_scan(const u8* __restrict__ src, con
     Lz4Unit u; u.blk = 0; u.bsz_seg = 0; u.entry = 0;
     if (idx < nu) u = units[idx];
     const bool ok = lz4_scan_units(shs, src, (u64)(read_hi - src), u.blk, u.bsz_seg & 0xFFFFFu, u.bsz_seg >> 20, tok, lane);
-    if (idx < nu && !ok) meta[u.entry] = 0u;                  // (a plain store: every writer writes 0)
+    if (idx < nu && !ok) meta[u.entry] = 2u;                  // not listed: a unit of it could not be
+}
+
+// ... seam repair, one LANE per unit: the chain across the seam behind the unit becomes exact ...
+__global__ __launch_bounds__(64) void k_lz4_seam(const u8* __restrict__ src, const u32* __restrict__ counters,
+                                                 const Lz4Unit* __restrict__ units, u8* __restrict__ tok, u32* __restrict__ meta)
+{
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= counters[C_LZ4_UNITS]) return;
+    const Lz4Unit u = units[idx];
+    if (meta[u.entry] != 1u) return;                          // (already given up: its lists may be incomplete)
+    if (!lz4_seam(src, u.blk, u.bsz_seg & 0xFFFFFu, u.bsz_seg >> 20, tok)) meta[u.entry] = 3u;    // a seam did not join
 }
 
 // ... then one WAVE per entry executes the listed sequences; whatever it does not finish goes on the leftover list
-__global__ __launch_bounds__(64, 7) void k_lz4_exec(const u8* __restrict__ src, const u8* read_hi,
+__global__ __launch_bounds__(64, LX_WAVES_PER_SIMD) void k_lz4_exec(const u8* __restrict__ src, const u8* read_hi,
                                                     const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                     zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
                                                     u32* __restrict__ counters, const u8* __restrict__ tok,
@@ -242,9 +256,10 @@ __global__ __launch_bounds__(64, 7) void k_lz4_exec(const u8* __restrict__ src, 
     if (!my_slot(counters, L_LZ4, idx)) return;
     const u32 e = uni(list[idx]);
     const zpk_decode_desc d = desc[e];
-    int why = 0;
+    const u32 verdict = uni(meta[e]);
+    int why = verdict == 2u ? 30 - C_LZ4_WHY : (verdict == 3u ? 31 - C_LZ4_WHY : 0);
     bool finished = false;
-    if (uni(meta[e]) == 1u) {
+    if (verdict == 1u) {
         const LxResult r = lz4f_exec_wave(shx, src, read_hi, uni64(d.src_offset), uni64(d.comp_size), tok, uni_ptr(dst + d.dst_offset),
                                           uni64(d.dst_capacity), uni64(d.uncomp_size), lane, dbg ? dbg + (u64)e * 16 : nullptr);
         why = r.rc;
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(64, 7) void k_lz4_exec(const u8* __restrict__ src, 
     lane0_guard();
     if (!finished && lane == 0) {
         leftover[atomicAdd(&counters[C_LZ4_LEFT], 1u)] = e;
-        atomicAdd(&counters[C_LZ4_WHY + (why < 0 || why > 8 ? 0 : why)], 1u);
+        atomicAdd(&counters[C_LZ4_WHY + (why < 0 || why > 11 || why == 9 ? 0 : why)], 1u);     // (slot 9 is C_LZ4_UNITS; 10, 11 = scan / seam)
     }
 }
 
@@ -428,6 +443,7 @@ struct zpk_codec {
     void* d_units = nullptr;     u64 units_cap = 0;    // decoder: scan units (lz4_ring.h)
     int lz4_hint = -1;           // host path: does the batch hold an LZ4 entry?  -1 = unknown (device path)
     int lz4_general_only = 0;    // the last decode batch could not get its token scratch: general LZ4 decoder only
+    int opt_lz4_ring = 0;        // ZPK_OPT_LZ4_RING: scan + ring executor in front of the general LZ4 decoder (lz4_ring.h)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t kev[ZPK_K_COUNT][2] = {};
     int profiling = 0;
@@ -583,7 +599,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     // LZ4: token scan (one lane per entry) -> ring executor (one wave per entry) -> the general decoder for whatever those two
     // did not finish (lz4_ring.h).  Without the token scratch the general decoder takes the whole list.
     const bool maybe_lz4 = c->lz4_hint != 0;
-    bool ring = maybe_lz4;
+    bool ring = maybe_lz4 && c->opt_lz4_ring;
     ZPK_DEV(static const int lz4_general = getenv("ZPK_LZ4_GENERAL") ? atoi(getenv("ZPK_LZ4_GENERAL")) : 0; if (lz4_general) ring = false;)
     c->lz4_general_only = 0;
     const u64 src_bytes = (u64)(read_hi - read_lo);
@@ -602,6 +618,8 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
         hipLaunchKernelGGL(k_lz4_frames, dim3((u32)((n + 63) / 64)), dim3(64), 0, st, src, read_lo, read_hi, desc,
                            c->d_lists + L_LZ4 * stride, c->d_counters, c->d_lz4meta, (Lz4Unit*)c->d_units, (u32)unit_cap);
         hipLaunchKernelGGL(k_lz4_scan, dim3((u32)((unit_cap + 63) / 64)), dim3(64), 0, st, src, read_hi, c->d_counters,
+                           (const Lz4Unit*)c->d_units, c->d_tok, c->d_lz4meta);
+        hipLaunchKernelGGL(k_lz4_seam, dim3((u32)((unit_cap + 63) / 64)), dim3(64), 0, st, src, c->d_counters,
                            (const Lz4Unit*)c->d_units, c->d_tok, c->d_lz4meta);
     }
     ZPK_KEV(ZPK_K_LZ4_SCAN, 1);
@@ -842,6 +860,7 @@ int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
     memset(out, 0, 16 * sizeof(uint32_t));
     out[0] = h[C_LZ4_RING]; out[1] = h[C_LZ4_LEFT];
     for (int i = 0; i < 9; i++) out[2 + i] = h[C_LZ4_WHY + i];
+    out[11] = h[30]; out[12] = h[31]; out[13] = h[C_LZ4_UNITS];
     return ZPK_OK;
 }
 
@@ -850,13 +869,23 @@ int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
 int zpk_codec_debug_fetch(zpk_codec* c, int what, uint64_t offset, void* host, uint64_t bytes)
 {
     if (!c || !host) return ZPK_E_INVALID;
-    const u8* base = what == 0 ? (const u8*)c->d_zarena : (const u8*)c->d_zstate;
-    const u64 cap = what == 0 ? c->zarena_cap : c->zstate_cap;
+    const u8* base = what == 0 ? (const u8*)c->d_zarena : what == 3 ? (const u8*)c->d_lz4meta : what == 4 ? (const u8*)c->d_units : what == 5 ? (const u8*)c->d_tok : (const u8*)c->d_zstate;
+    const u64 cap = what == 0 ? c->zarena_cap : what == 3 ? c->lz4meta_cap : what == 4 ? c->units_cap : what == 5 ? c->tok_cap : c->zstate_cap;
     if (!base || offset > cap || bytes > cap - offset) return ZPK_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(host, base + offset, bytes, hipMemcpyDeviceToHost));
     return ZPK_OK;
+}
+
+int zpk_codec_set_option(zpk_codec* c, int option, int value)
+{
+    if (!c) return ZPK_E_INVALID;
+    CodecLock lk(c);
+    switch (option) {
+    case ZPK_OPT_LZ4_RING: c->opt_lz4_ring = value ? 1 : 0; return ZPK_OK;
+    default: return ZPK_E_INVALID;
+    }
 }
 
 int zpk_codec_set_profiling(zpk_codec* c, int enabled)
