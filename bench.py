@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py — batch entry decode on MI355X: decompressed GiB/s over all entries + % of HBM roofline.
+"""bench.py — the batch entry codec on MI355X: GiB/s over all entries + % of HBM roofline, CPU reference beside it.
 
-A "step" is one pass of the hot path (guards -> per-entry decode -> fused XXH3 verify) over one batch
-of synthetic archive entries that is already resident in HBM.  Default workload = BASELINE.json
-configs[1]: 100k x 64 KiB LZ4-frame entries (lz4 level 0, seeded 70/20/5/5 text/records/random/runs
-mix, frames produced by the real liblz4 with the reference writer's call sequence).
+A "step" is one pass of the hot path over one batch of synthetic entries that is already resident in HBM:
+  decode workloads   guards -> per-entry decode -> XXH3 verify (zpk_codec_decode_batch_device)
+  c5_zstd1_1m        compress + XXH3 of the source + size scan + compaction (zpk_codec_encode_batch_device + _pack_batch_device)
+Default workload = BASELINE.json configs[1]: 100k x 64 KiB LZ4-frame entries (lz4 level 0, seeded 70/20/5/5
+text/records/random/runs mix, frames produced by the real liblz4 with the reference writer's call sequence).
 
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--workload ...] [--scaling weak|strong]
+  (N > 1: launched by torch.distributed.run, one rank per GPU; the only communication is the barrier, the max-reduce of the
+   timing and — strong scaling — the gather of the per-entry results on rank 0: entries are independent)
 
-Prints ONE JSON line (rank 0).  `value` = decompressed bytes of all ranks / max-over-ranks wall time of
-the K timed steps (barrier + synchronize on both sides).  `roofline` is for the dominant kernel,
-measured with HIP events on the launch stream; `cpu_baseline` is the compiled reference
-(oracle/_ref, zpack_read_file per entry, one context per thread) on a bounded sample of the same archive.
+Prints ONE JSON line (rank 0).  `value` = bytes of all ranks / max-over-ranks wall time of the K timed steps (barrier +
+synchronize on both sides).  `roofline` is for the dominant kernel(s), timed with HIP events on the launch stream inside the last
+timed step; `cpu_baseline` is the COMPILED REFERENCE (oracle/_ref) on a bounded sample of the same data, at one thread and at all
+cores of the box.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -27,40 +31,61 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (achievable ~6.3 TB/s)
 
 WORKLOADS = {
-    # name: (entries, size_lo, size_hi, method, level, seed, dominant kernel)
-    "c2_lz4_64k": dict(n=100000, lo=65536, hi=65536, method=2, level=0, seed=1, kernel="lz4"),
-    "c3_zstd_256k": dict(n=100000, lo=262144, hi=262144, method=1, level=3, seed=2, kernel="zstd"),
-    "c4_mixed": dict(n=125000, lo=4096, hi=1048576, method=-1, level=3, seed=3, kernel="zstd"),
-    "stored_64k": dict(n=100000, lo=65536, hi=65536, method=0, level=0, seed=5, kernel="stored"),
+    # decode: entries, size range, method (-1 = LZ4/Zstandard coin), level, seed, dominant kernel
+    "c2_lz4_64k": dict(kind="decode", n=100000, lo=65536, hi=65536, method=2, level=0, seed=1, kernel="lz4"),
+    "c3_zstd_256k": dict(kind="decode", n=100000, lo=262144, hi=262144, method=1, level=3, seed=2, kernel="zstd"),
+    "c4_mixed": dict(kind="decode", n=125000, lo=4096, hi=1048576, method=-1, level=3, seed=3, kernel="zstd"),
+    "stored_64k": dict(kind="decode", n=100000, lo=65536, hi=65536, method=0, level=0, seed=5, kernel="stored"),
+    # encode: BASELINE.json configs[4] per GPU (100k x 1 MiB over 8 GPUs = 12 500 per GPU), Zstandard level 1 + XXH3
+    "c5_zstd1_1m": dict(kind="encode", n=12500, lo=1 << 20, hi=1 << 20, method=1, level=1, seed=4, kernel="encode"),
 }
+KNAMES = {"lz4": ["k_lz4_wave"], "lz4_ring": ["k_lz4_frames", "k_lz4_scan", "k_lz4_seam", "k_lz4_exec", "k_lz4_wave"],
+          "zstd": ["k_zstd_fse", "k_zstd_exec", "k_zstd"], "stored": ["k_stored"], "encode": ["k_encode"]}
 
 
-def cpu_baseline(batch, seconds, threads):
-    """The reference's own read path on the host cores (kind 'reference'); oracle port if _ref is absent."""
-    import numpy as np
-    ref_drv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
+def csrc_sha1():
+    """identity of the kernel sources: a committed PMC summary describes THIS code only if it carries the same value"""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "zpack_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def _ref_driver():
+    p = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
+    return C.CDLL(p) if os.path.exists(p) else None
+
+
+def cpu_baseline_decode(batch, seconds, ncores):
+    """zpack_read_file of the compiled reference (decode + XXH3 verify), one context per thread, at 1 thread and at all cores"""
     n = batch.n
-    # bounded sample: the first entries up to ~1 GiB decompressed per thread-second budget
     sample = min(n, max(256, int(2e9 * seconds / 10 / max(1, int(batch.uncomp_sizes[:64].mean())))))
-    if os.path.exists(ref_drv):
-        L = C.CDLL(ref_drv)
+    L = _ref_driver()
+    if L is not None:
         L.ref_baseline_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.POINTER(C.c_double)]
-        out = (C.c_double * 4)()
-        rc = L.ref_baseline_decode(batch.archive.ctypes.data, batch.archive.size, 0, sample, threads, float(seconds), out)
-        if rc == 0 and out[2] == 0:
-            return dict(value=out[0] / out[1] / 2**30, unit="GiB/s", cores=threads, kind="reference",
-                        sample="zpack_read_file (decode + XXH3 verify) of the compiled reference over the first %d entries of "
-                               "the same archive, %d thread(s), looped for %.1f s (%.2f GiB decoded)" %
-                               (sample, threads, out[1], out[0] / 2**30))
-        why = "reference driver rc=%d errors=%d; " % (rc, int(out[2]))
-    else:
-        why = "oracle/_ref not built; "
+        legs = {}
+        for threads, secs in ((1, max(2.0, seconds * 0.3)), (ncores, max(3.0, seconds * 0.7))):
+            out = (C.c_double * 4)()
+            rc = L.ref_baseline_decode(batch.archive.ctypes.data, batch.archive.size, 0, sample if threads > 1 else min(sample, 2048),
+                                       threads, float(secs), out)
+            if rc != 0 or out[2] != 0:
+                legs = None
+                break
+            legs[threads] = (out[0] / out[1] / 2**30, out[1], out[0] / 2**30)
+        if legs:
+            v, dt, gib = legs[ncores]
+            return dict(value=v, unit="GiB/s", cores=ncores, kind="reference",
+                        sample="zpack_read_file (decode + XXH3 verify) of the compiled reference over the first %d entries of the same "
+                               "archive, %d threads, looped for %.1f s (%.2f GiB decoded)" % (sample, ncores, dt, gib),
+                        one_thread=dict(value=legs[1][0], unit="GiB/s", cores=1,
+                                        sample="same call, 1 thread, first %d entries, %.1f s" % (min(sample, 2048), legs[1][1])))
     from tests._libs import oracle
     o = oracle()
     arc = batch.archive.tobytes() if batch.archive.size < (1 << 31) else None
     t0 = time.time()
-    done = 0
-    i = 0
+    done = i = 0
     while time.time() - t0 < seconds and arc is not None:
         k = i % sample
         o.entry_decode(arc, int(batch.offsets[k]), int(batch.comp_sizes[k]), int(batch.uncomp_sizes[k]), int(batch.hashes[k]),
@@ -69,7 +94,56 @@ def cpu_baseline(batch, seconds, threads):
         i += 1
     dt = time.time() - t0
     return dict(value=done / dt / 2**30, unit="GiB/s", cores=1, kind="port",
-                sample=why + "oracle/liboracle.so entry_decode over %d entries, 1 thread, %.1f s" % (i, dt))
+                sample="oracle/_ref not built; oracle/liboracle.so entry_decode over %d entries, 1 thread, %.1f s" % (i, dt))
+
+
+def cpu_baseline_encode(plain, entry_size, method, level, seconds, ncores):
+    """zpack_write_files of the compiled reference (lib/zpack_write.c:280-343), heap writer per thread, 1 thread and all cores"""
+    L = _ref_driver()
+    count = plain.size // entry_size
+    if L is None or not hasattr(L, "ref_baseline_encode"):
+        return dict(value=None, unit="GiB/s", cores=0, kind="port", sample="oracle/_ref not built: no CPU write-path baseline")
+    L.ref_baseline_encode.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]
+    legs = {}
+    for threads, secs in ((1, max(2.0, seconds * 0.3)), (ncores, max(3.0, seconds * 0.7))):
+        out = (C.c_double * 4)()
+        cnt = min(count, 8 * threads if threads > 1 else 16)
+        L.ref_baseline_encode(plain.ctypes.data, entry_size, cnt, method, level, threads, float(secs), out)
+        legs[threads] = (out[0] / out[1] / 2**30, out[1], out[3] / max(out[0], 1.0), int(out[2]), cnt)
+    v, dt, ratio, errs, cnt = legs[ncores]
+    return dict(value=v, unit="GiB/s", cores=ncores, kind="reference", ratio=ratio, errors=errs,
+                sample="zpack_write_files (compress + XXH3 + append) of the compiled reference over the first %d sources, %d threads, "
+                       "looped for %.1f s; compressed/source = %.3f" % (cnt, ncores, dt, ratio),
+                one_thread=dict(value=legs[1][0], unit="GiB/s", cores=1, ratio=legs[1][2],
+                                sample="same call, 1 thread, first %d sources, %.1f s" % (legs[1][4], legs[1][1])))
+
+
+def pmc_traffic(workload, n, knames, sha):
+    """HBM traffic per launch from the committed rocprofv3 --pmc summary of THIS workload, size and kernel sources (tools/pmc.sh,
+    separate FETCH_SIZE / WRITE_SIZE passes); None when no summary matches — never a figure measured on other code."""
+    note = "no committed PMC summary for this workload / size / kernel sources (csrc sha1 %s)" % sha[:12]
+    try:
+        for rd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            f = os.path.join(ROOT, "profiles", rd, "pmc_%s.json" % workload)
+            if not os.path.exists(f):
+                continue
+            pm = json.load(open(f))
+            ks = [pm["kernels"][x] for x in knames if x in pm.get("kernels", {})]
+            if pm.get("entries_per_gpu") != n or not ks:
+                continue
+            if pm.get("csrc_sha1") != sha:
+                note = "%s was measured on other kernel sources (csrc sha1 %s, now %s): not quoted" % (
+                    os.path.relpath(f, ROOT), str(pm.get("csrc_sha1"))[:12], sha[:12])
+                continue
+            fs, ws = sum(k["FETCH_SIZE_bytes"] for k in ks), sum(k["WRITE_SIZE_bytes"] for k in ks)
+            # MI355X_MICROARCH.md, HBM: FETCH_SIZE tallies 64 B per 128-B request for wide coalesced streaming reads (x2 there); scattered
+            # 16-byte gathers are uncalibrated, so both bounds are given; WRITE_SIZE is exact for 16-B-per-lane stores
+            return dict(traffic=2.0 * fs + ws, fetch_raw=fs, write=ws, low=fs + ws,
+                        note="%s: FETCH_SIZE %.3g B raw (x2 for streaming reads = %.3g) + WRITE_SIZE %.3g B, mean per launch; "
+                             "traffic is between %.3g (raw) and %.3g (x2) bytes" % (os.path.relpath(f, ROOT), fs, 2 * fs, ws, fs + ws, 2 * fs + ws))
+    except Exception as ex:
+        note = "PMC summary unreadable: %s" % ex
+    return dict(traffic=None, fetch_raw=None, write=None, low=None, note=note)
 
 
 def main():
@@ -78,18 +152,21 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2_lz4_64k", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank decodes its own batch; strong: ONE archive, statically sharded by bytes over the ranks")
     ap.add_argument("--entries", type=int, default=0, help="override the entry count (debug; the line then names it)")
     ap.add_argument("--mix", type=int, default=-1, help="-1 = 70/20/5/5 class mix, 0..3 = single class")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--lz4-ring", action="store_true", help="LZ4 entries through the scan + LDS-ring executor first (zpk_codec_set_option ZPK_OPT_LZ4_RING)")
-    ap.add_argument("--skip-hash", action="store_true", help="diagnostic only: decode without the XXH3 verify (the line says so)")
+    ap.add_argument("--lz4-ring", action="store_true", help="LZ4 entries through the scan + LDS-ring executor first (ZPK_OPT_LZ4_RING)")
+    ap.add_argument("--skip-hash", action="store_true", help="diagnostic only: status ignores the XXH3 verdict (the line says so)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import zpack_amd
     from benchdata import datagen as dg
+    from zpack_amd.shard import shard_ranges, gather_results
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +176,7 @@ def main():
     rehearsal = os.environ.get("ZPK_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -112,28 +190,15 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.entries:
         w["n"] = args.entries
+    strong = args.scaling == "strong" and w["kind"] == "decode"
     ncores = len(os.sched_getaffinity(0))
     gen_threads = max(1, ncores // max(1, world))
-
-    # ---- synthetic archive: independent entries; weak scaling = every rank decodes its own batch ----
-    t0 = time.time()
-    batch = dg.Batch(w["n"], w["lo"], w["hi"], method=w["method"], level=w["level"], seed=w["seed"] + 1000 * rank,
-                     mix=args.mix, threads=gen_threads)
-    t_gen = time.time() - t0
-    desc, dst_bytes = zpack_amd.decode_descs_from_batch(batch, flags=zpack_amd.DF_SKIP_HASH if args.skip_hash else 0)
-    n = batch.n
-
     codec = zpack_amd.Codec(local_rank)
     if args.lz4_ring:
         codec.set_option(zpack_amd.OPT_LZ4_RING, 1)
-    src = torch.from_numpy(batch.archive).to(dev)
-    dst = torch.empty(dst_bytes, dtype=torch.uint8, device=dev)
-    ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
-    dres = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        codec.decode_batch_device(src, ddesc, n, dst, dres, stream)
+    sha = csrc_sha1()
+    red_dev = torch.device("cpu") if rehearsal else dev
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,120 +206,257 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    codec.timer_start(stream)
-    for _ in range(args.steps):
-        step()
-    ev_ms = codec.timer_stop(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    def allsum(vals):
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
+    def allmax(v):
+        if world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        tot = torch.tensor([float(batch.total_uncomp), float(batch.total_comp)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_uncomp, total_comp = float(tot[0].item()), float(tot[1].item())
+        return float(t.item())
+
+    def timed(step):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        codec.set_profiling(True)                               # per-kernel HIP events inside the timed launches themselves
+        t0 = time.perf_counter()
+        codec.timer_start(stream)
+        for _ in range(args.steps):
+            step()
+        ev_ms = codec.timer_stop(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+        return allmax(wall), ev_ms
+
+    # ---- the copy ceiling of THIS build on THIS box: the stored-entry kernel (copy + XXH3 fused) on a 1 GiB batch ----
+    def copy_ceiling():
+        sb = dg.Batch(16384, 65536, 65536, method=0, level=0, seed=77, threads=gen_threads)
+        sd, stot = zpack_amd.decode_descs_from_batch(sb)
+        s_src = torch.from_numpy(sb.archive).to(dev)
+        s_dst = torch.empty(stot, dtype=torch.uint8, device=dev)
+        s_desc = torch.from_numpy(sd.view(np.uint8)).to(dev)
+        s_res = torch.zeros(sb.n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        codec.set_profiling(True)
+        ms = []
+        for _ in range(4):
+            codec.decode_batch_device(s_src, s_desc, sb.n, s_dst, s_res, stream)
+            ms.append(codec.kernel_ms(zpack_amd.K_STORED))
+        codec.set_profiling(False)
+        ok = bool((s_res.cpu().numpy().view(zpack_amd.DECODE_RESULT)["status"] == 0).all())
+        return 2.0 * sb.total_uncomp / (min(ms[1:]) * 1e-3) / 1e9 if ok else None
+
+    out = None
+    parity = True
+    if w["kind"] == "decode":
+        # ---- synthetic archive.  weak: every rank its own batch; strong: the SAME archive everywhere, one byte-balanced slice per rank ----
+        t0 = time.time()
+        seed = w["seed"] + (0 if strong else 1000 * rank)
+        batch = dg.Batch(w["n"], w["lo"], w["hi"], method=w["method"], level=w["level"], seed=seed, mix=args.mix, threads=gen_threads)
+        t_gen = time.time() - t0
+        flags = zpack_amd.DF_SKIP_HASH if args.skip_hash else 0
+        if strong:
+            lo, hi = shard_ranges(batch.comp_sizes, batch.uncomp_sizes, world)[rank]
+        else:
+            lo, hi = 0, batch.n
+
+        class _Slice:                                   # the rank's contiguous range of the CDR order
+            n = hi - lo
+            offsets, comp_sizes, uncomp_sizes = batch.offsets[lo:hi], batch.comp_sizes[lo:hi], batch.uncomp_sizes[lo:hi]
+            hashes, methods = batch.hashes[lo:hi], batch.methods[lo:hi]
+        desc, dst_bytes = zpack_amd.decode_descs_from_batch(_Slice, flags=flags)
+        n = hi - lo
+        src = torch.from_numpy(batch.archive).to(dev)
+        dst = torch.empty(max(dst_bytes, 1), dtype=torch.uint8, device=dev)
+        ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+        dres = torch.zeros(max(n, 1) * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+
+        def step():
+            codec.decode_batch_device(src, ddesc, n, dst, dres, stream)
+
+        wall, ev_ms = timed(step)
+        kern = "lz4_ring" if (w["kernel"] == "lz4" and args.lz4_ring) else w["kernel"]
+        kids = dict(lz4=[zpack_amd.K_LZ4], lz4_ring=[zpack_amd.K_LZ4_SCAN, zpack_amd.K_LZ4], zstd=[zpack_amd.K_ZSTD_FSE, zpack_amd.K_ZSTD],
+                    stored=[zpack_amd.K_STORED])[kern]
+        stage_ms = [codec.kernel_ms(k) for k in kids] if n else [0.0]      # the LAST timed launch's kernels
+        codec.set_profiling(False)
+        dstats = codec.decode_stats()
+        my_uncomp = float(_Slice.uncomp_sizes.sum()) if n else 0.0
+        my_comp = float(_Slice.comp_sizes.sum()) if n else 0.0
+        total_uncomp, total_comp = allsum([my_uncomp, my_comp])
+
+        # ---- parity gate: every status, every XXH3, sizes, and the bytes of a sample against the oracle ----
+        res_local = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)[:n]
+        if strong and world > 1:
+            res = gather_results(res_local, lo, hi, batch.n, rank, world, dist)      # rank 0: the whole archive's results, CDR order
+            ref_hashes, ref_sizes = batch.hashes, batch.uncomp_sizes
+        else:
+            res, ref_hashes, ref_sizes = res_local, _Slice.hashes, _Slice.uncomp_sizes
+        bad, hash_ok, size_ok = 0, True, True
+        if res is not None:
+            bad = int((res["status"] != 0).sum())
+            hash_ok = bool(np.array_equal(res["hash"], ref_hashes))
+            size_ok = bool(np.array_equal(res["produced"], ref_sizes))
+        bytes_ok = True
+        try:
+            from tests._libs import oracle
+            o = oracle()
+            rng = np.random.default_rng(1234)
+            for i in (rng.choice(n, size=min(n, 24), replace=False) if n else []):
+                d = desc[i]
+                off, cs = int(d["src_offset"]), int(d["comp_size"])
+                arc = bytes(b"\0" * 10) + batch.archive[off:off + cs].tobytes() + b"\0"
+                rc, want, got, h = o.entry_decode(arc, 10, cs, int(d["uncomp_size"]), int(d["expect_hash"]), int(d["method"]),
+                                                  int(d["dst_capacity"]))
+                have = dst[int(d["dst_offset"]):int(d["dst_offset"]) + int(d["uncomp_size"])].cpu().numpy().tobytes()
+                if rc != 0 or have != want:
+                    bytes_ok = False
+        except Exception as ex:                                   # the checker is optional at run time, the hash gate is not
+            bytes_ok = "oracle unavailable: %s" % ex
+        parity = bad == 0 and hash_ok and size_ok and bytes_ok is True
+        parity = allsum([0.0 if parity else 1.0])[0] == 0.0
+        if not parity:
+            print("PARITY FAILURE rank %d: bad_status=%d hash_ok=%s size_ok=%s bytes_ok=%s" % (rank, bad, hash_ok, size_ok, bytes_ok),
+                  file=sys.stderr)
+
+        k_ms = float(sum(stage_ms))
+        alg_bytes = my_comp + my_uncomp                                    # each byte moved once, this rank's launch
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        if rank == 0:
+            ceiling = copy_ceiling()
+            tr = pmc_traffic(args.workload, n, KNAMES[kern], sha)
+            cpu = None
+            if not args.no_cpu and world == 1:                      # the CPU leg is reported at N=1 only
+                cpu = cpu_baseline_decode(batch, args.cpu_seconds, ncores)
+            out = {
+                "metric": "decompressed GiB/s over all entries; % HBM roofline" + (" [DIAGNOSTIC: hash verdict ignored]" if args.skip_hash else ""),
+                "value": total_uncomp * args.steps / wall / 2**30, "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": args.workload, "entries_per_gpu": n, "entries_total": batch.n if strong else n * world,
+                           "entry_bytes": [w["lo"], w["hi"]],
+                           "method": {0: "none", 1: "zstd", 2: "lz4", -1: "lz4+zstd coin"}[w["method"]], "level": w["level"],
+                           "class_mix": "70/20/5/5 text/records/random/runs" if args.mix < 0 else ["text", "records", "random", "runs"][args.mix],
+                           "comp_ratio": total_comp / max(total_uncomp, 1.0),
+                           "parallelism": ("one archive, static shard by bytes (zpack_amd/shard.py), results gathered on rank 0" if strong
+                                           else "one batch per rank") + ", no data-path collective",
+                           "lz4_path": "scan + ring executor, general decoder behind it" if args.lz4_ring else "general decoder",
+                           "frames_by": "liblz4/libzstd of the image, reference writer call sequence", "gen_seconds": round(t_gen, 1)},
+                "parity": {"all_status_ok": bad == 0, "xxh3_equal_real_xxhash": hash_ok, "sizes_equal": size_ok,
+                           "bytes_equal_oracle_sample": bytes_ok, "all_ranks": parity},
+                "event_ms_per_step": ev_ms / args.steps,
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "copy_ceiling_gbs": ceiling, "frac_of_copy_ceiling": (achieved / ceiling) if ceiling else None,
+                             "copy_ceiling_source": "k_stored (copy + XXH3 fused) of this build on a 1 GiB stored batch, read + write bytes / "
+                                                    "HIP-event time, same process",
+                             "traffic": tr["traffic"], "traffic_fetch_raw": tr["fetch_raw"], "traffic_write": tr["write"],
+                             "traffic_source": tr["note"], "csrc_sha1": sha, "kernel": "+".join(KNAMES[kern]),
+                             "kernel_ms": k_ms, "stage_ms": stage_ms, "kernel_ms_source": "HIP events around the kernels of the last timed step",
+                             "algorithmic_bytes_per_launch": alg_bytes},
+                "decode_stats": dstats,
+                "cpu_baseline": cpu,
+            }
     else:
-        total_uncomp, total_comp = float(batch.total_uncomp), float(batch.total_comp)
+        # ---- C5: the write path.  Sources resident in HBM; timed = encode batch + size scan + compaction (lib/zpack_write.c:280-343) ----
+        n, size, method, level = w["n"], w["lo"], w["method"], w["level"]
+        t0 = time.time()
+        rng = np.random.default_rng(w["seed"] + 1000 * rank)
+        classes = rng.choice(4, size=n, p=[0.70, 0.20, 0.05, 0.05]) if args.mix < 0 else np.full(n, args.mix)
+        plain = np.empty(n * size, dtype=np.uint8)
+        for i in range(n):
+            plain[i * size:(i + 1) * size] = dg.fill(int(classes[i]), w["seed"] + 1000 * rank, i, size)
+        t_gen = time.time() - t0
+        bound = codec.compress_bound(method, size)
+        slot = (bound + 255) & ~255
+        desc = np.zeros(n, dtype=zpack_amd.ENCODE_DESC)
+        desc["src_offset"] = np.arange(n, dtype=np.uint64) * size
+        desc["size"] = size
+        desc["dst_offset"] = np.arange(n, dtype=np.uint64) * slot
+        desc["dst_capacity"] = bound
+        desc["method"] = method
+        desc["level"] = level
+        src = torch.from_numpy(plain).to(dev)
+        ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+        slots = torch.empty(n * slot, dtype=torch.uint8, device=dev)
+        dres = torch.zeros(n * zpack_amd.ENCODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        packed = torch.empty(n * bound + 64, dtype=torch.uint8, device=dev)
 
-    # ---- parity gate: every status, every XXH3, and bytes of a sample against the oracle ----
-    res = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)
-    bad = int((res["status"] != 0).sum())
-    hash_ok = bool(np.array_equal(res["hash"], batch.hashes)) or args.skip_hash
-    size_ok = bool(np.array_equal(res["produced"], batch.uncomp_sizes))
-    bytes_ok = True
-    try:
-        from tests._libs import oracle
-        o = oracle()
-        rng = np.random.default_rng(1234)
-        for i in rng.choice(n, size=min(n, 24), replace=False):
-            d = desc[i]
-            off, cs = int(d["src_offset"]), int(d["comp_size"])
-            arc = bytes(b"\0" * 10) + batch.archive[off:off + cs].tobytes() + b"\0"
-            rc, want, got, h = o.entry_decode(arc, 10, cs, int(d["uncomp_size"]), int(d["expect_hash"]), int(d["method"]),
-                                              int(d["dst_capacity"]))
-            have = dst[int(d["dst_offset"]):int(d["dst_offset"]) + int(d["uncomp_size"])].cpu().numpy().tobytes()
-            if rc != 0 or have != want:
-                bytes_ok = False
-    except Exception as ex:                                   # the checker is optional at run time, the hash gate is not
-        bytes_ok = "oracle unavailable: %s" % ex
-    parity = bad == 0 and hash_ok and size_ok and bytes_ok is True
-    if not parity:
-        print("PARITY FAILURE rank %d: bad_status=%d hash_ok=%s size_ok=%s bytes_ok=%s" % (rank, bad, hash_ok, size_ok, bytes_ok),
-              file=sys.stderr)
+        def step():
+            codec.encode_batch_device(src, ddesc, n, slots, dres, stream)
+            codec.pack_batch_device(slots, ddesc, dres, n, packed, offs, int(bound), stream)
 
-    # ---- dominant-kernel time, HIP events on the launch stream ----
-    # (Zstandard runs as a pipeline: k_zstd_fse pre-decodes the sequence streams, k_zstd_exec + k_zstd do the rest;
-    # its figure is the sum of the stages, bracketed on the stream one after the other)
-    kids = dict(lz4=[zpack_amd.K_LZ4_SCAN, zpack_amd.K_LZ4], zstd=[zpack_amd.K_ZSTD_FSE, zpack_amd.K_ZSTD], stored=[zpack_amd.K_STORED])[w["kernel"]]
-    codec.set_profiling(True)
-    kms, stage_ms = [], None
-    for _ in range(max(3, min(args.steps, 10))):
-        step()
-        stage_ms = [codec.kernel_ms(k) for k in kids]
-        kms.append(sum(stage_ms))
-    codec.set_profiling(False)
-    dstats = codec.decode_stats()
-    k_ms = float(np.mean(kms))
-    alg_bytes = float(batch.total_comp + batch.total_uncomp)            # each byte moved once
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-
-    # HBM traffic of the dominant kernel: hardware counters cannot be read from inside this process, so the
-    # figure comes from the committed rocprofv3 --pmc summary of THIS workload at THIS size (tools/pmc.sh,
-    # separate FETCH_SIZE / WRITE_SIZE passes); null when no matching measurement is committed.
-    traffic, traffic_note = None, "no committed PMC summary for this workload/size"
-    knames = {"lz4": ["k_lz4_wave"], "zstd": ["k_zstd_fse", "k_zstd_exec", "k_zstd"], "stored": ["k_stored"]}[w["kernel"]]
-    kname = "+".join(knames)
-    try:
-        for rd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-            f = os.path.join(ROOT, "profiles", rd, "pmc_%s.json" % args.workload)
-            if os.path.exists(f):
-                pm = json.load(open(f))
-                ks = [pm["kernels"][x] for x in knames if x in pm.get("kernels", {})]
-                if pm.get("entries_per_gpu") == n and ks:
-                    # MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts 64 B per 128-B request on gfx950 (x2); WRITE_SIZE is exact
-                    fs, ws = sum(k["FETCH_SIZE_bytes"] for k in ks), sum(k["WRITE_SIZE_bytes"] for k in ks)
-                    traffic = 2.0 * fs + ws
-                    traffic_note = "%s: 2 x FETCH_SIZE (%.3g B raw) + WRITE_SIZE (%.3g B), mean per launch" % (os.path.relpath(f, ROOT), fs, ws)
-                break
-    except Exception as ex:
-        traffic_note = "PMC summary unreadable: %s" % ex
-
-    if rank == 0:
-        cpu = None
-        if not args.no_cpu and world == 1:                      # the CPU leg is reported at N=1 only
-            cpu = cpu_baseline(batch, args.cpu_seconds, ncores)
-        out = {
-            "metric": "decompressed GiB/s over all entries; % HBM roofline" + (" [DIAGNOSTIC: hash skipped]" if args.skip_hash else ""),
-            "value": total_uncomp * args.steps / wall / 2**30,
-            "unit": "GiB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "entries_per_gpu": n, "entry_bytes": [w["lo"], w["hi"]],
-                       "method": {0: "none", 1: "zstd", 2: "lz4", -1: "lz4+zstd coin"}[w["method"]], "level": w["level"],
-                       "class_mix": "70/20/5/5 text/records/random/runs" if args.mix < 0 else ["text", "records", "random", "runs"][args.mix],
-                       "comp_ratio": total_comp / total_uncomp, "parallelism": "static shard, no collectives",
-                       "frames_by": "liblz4/libzstd of the image, reference writer call sequence", "gen_seconds": round(t_gen, 1)},
-            "parity": {"all_status_ok": bad == 0, "xxh3_equal_real_xxhash": hash_ok, "sizes_equal": size_ok,
-                       "bytes_equal_oracle_sample": bytes_ok},
-            "event_ms_per_step": ev_ms / args.steps,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_note, "kernel": kname,
-                         "kernel_ms": k_ms, "stage_ms": stage_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "decode_stats": dstats,
-            "cpu_baseline": cpu,
-        }
+        wall, ev_ms = timed(step)
+        stage_ms = [codec.kernel_ms(zpack_amd.K_ENCODE), codec.kernel_ms(zpack_amd.K_PACK)]
+        codec.set_profiling(False)
+        res = dres.cpu().numpy().view(zpack_amd.ENCODE_RESULT)
+        ho = offs.cpu().numpy().view(np.uint64)
+        total_c = int(ho[-1])
+        ok_status = bool((res["status"] == 0).all())
+        # ---- parity gate: every frame decoded back by the GPU decoder (bytes + XXH3), a sample by the oracle, hashes vs real xxHash ----
+        dd = np.zeros(n, dtype=zpack_amd.DECODE_DESC)
+        dd["src_offset"] = ho[:-1]; dd["comp_size"] = res["comp_size"]; dd["uncomp_size"] = size; dd["expect_hash"] = res["hash"]
+        dd["dst_offset"] = np.arange(n, dtype=np.uint64) * size; dd["dst_capacity"] = size; dd["method"] = method
+        back = torch.empty(n * size, dtype=torch.uint8, device=dev)
+        r2 = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        codec.decode_batch_device(packed[:total_c + 64], torch.from_numpy(dd.view(np.uint8)).to(dev), n, back, r2, stream)
+        torch.cuda.synchronize()
+        rr = r2.cpu().numpy().view(zpack_amd.DECODE_RESULT)
+        rt_ok = bool((rr["status"] == 0).all() and np.array_equal(rr["hash"], res["hash"]) and torch.equal(back, src))
+        hash_ok = all(int(res["hash"][i]) == dg.xxh3(plain[i * size:(i + 1) * size]) for i in range(0, n, max(1, n // 24)))
+        orc_ok = True
+        try:
+            from tests._libs import oracle
+            o = oracle()
+            hp = packed[:total_c].cpu().numpy()
+            for i in range(0, n, max(1, n // 8)):
+                fr = hp[int(ho[i]):int(ho[i]) + int(res["comp_size"][i])].tobytes()
+                rc, outb = (o.zstd_decode if method == 1 else o.lz4f_decode)(fr, size)
+                if rc != 0 or outb != plain[i * size:(i + 1) * size].tobytes():
+                    orc_ok = False
+        except Exception as ex:
+            orc_ok = "oracle unavailable: %s" % ex
+        parity = ok_status and rt_ok and hash_ok and orc_ok is True
+        parity = allsum([0.0 if parity else 1.0])[0] == 0.0
+        total_src, total_comp = allsum([float(n) * size, float(total_c)])
+        k_ms = float(stage_ms[0])
+        alg_bytes = float(n) * size + float(total_c)                        # source read once + compressed written once
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        if rank == 0:
+            ceiling = copy_ceiling()
+            tr = pmc_traffic(args.workload, n, KNAMES["encode"], sha)
+            cpu = None
+            if not args.no_cpu and world == 1:
+                cpu = cpu_baseline_encode(plain, size, method, level, args.cpu_seconds, ncores)
+            out = {
+                "metric": "compressed-source GiB/s (zpack_write path: Zstd-1 + XXH3); % HBM roofline",
+                "value": total_src * args.steps / wall / 2**30, "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": args.workload, "entries_per_gpu": n, "entry_bytes": [size, size], "method": "zstd" if method == 1 else "lz4",
+                           "level": level, "class_mix": "70/20/5/5 text/records/random/runs" if args.mix < 0 else ["text", "records", "random", "runs"][args.mix],
+                           "comp_ratio": total_comp / total_src, "reference_ratio": (cpu or {}).get("ratio"),
+                           "timed": "zpk_codec_encode_batch_device + zpk_codec_pack_batch_device (size scan + compaction = write_offset += comp_size)",
+                           "parallelism": "one batch per rank, no data-path collective", "gen_seconds": round(t_gen, 1)},
+                "parity": {"all_status_ok": ok_status, "gpu_decoder_round_trip_bytes_and_xxh3": rt_ok, "xxh3_equal_real_xxhash_sample": hash_ok,
+                           "oracle_decodes_sample": orc_ok, "all_ranks": parity},
+                "event_ms_per_step": ev_ms / args.steps,
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "copy_ceiling_gbs": ceiling, "frac_of_copy_ceiling": (achieved / ceiling) if ceiling else None,
+                             "copy_ceiling_source": "k_stored (copy + XXH3 fused) of this build on a 1 GiB stored batch, same process",
+                             "traffic": tr["traffic"], "traffic_fetch_raw": tr["fetch_raw"], "traffic_write": tr["write"],
+                             "traffic_source": tr["note"], "csrc_sha1": sha, "kernel": "k_encode", "kernel_ms": k_ms,
+                             "stage_ms": stage_ms, "stage_names": ["k_encode", "k_pack_gather"],
+                             "kernel_ms_source": "HIP events around the kernels of the last timed step",
+                             "algorithmic_bytes_per_launch": alg_bytes},
+                "cpu_baseline": cpu,
+            }
+    if rank == 0 and out is not None:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

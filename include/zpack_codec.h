@@ -165,7 +165,7 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
  * with HIP events on the launch stream; zpk_codec_kernel_ms then returns the duration of kernel
  * `which` (ZPK_K_*) in the most recent batch (synchronises on that batch). */
 enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2 /* k_lz4_exec + k_lz4_wave */, ZPK_K_ZSTD = 3, ZPK_K_ZSTD_FSE = 4, ZPK_K_PACK = 5,
-       ZPK_K_LZ4_SCAN = 6, ZPK_K_COUNT = 7 };
+       ZPK_K_LZ4_SCAN = 6, ZPK_K_ENCODE = 7, ZPK_K_COUNT = 8 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
 /* zpk_codec_decode_stats2: out[0] = LZ4 entries finished by the ring path, out[1] = left to the general decoder, out[2..10] = the
  * leftovers by reason (0 not a plain frame, then LX_E_* of lz4_ring.h), out[11] a unit could not be listed, out[12] a seam did not

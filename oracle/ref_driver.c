@@ -81,3 +81,54 @@ int ref_baseline_decode(uint8_t* archive, size_t size, uint64_t first, uint64_t 
     zpack_close_reader(&r);
     return 0;
 }
+
+/* ---- write path: zpack_write_files of the reference (lib/zpack_write.c:280-343: bound -> compress -> XXH3 -> append) ---- */
+typedef struct {
+    uint8_t* plain; uint64_t entry_size, lo, hi; int method, level; double seconds;
+    uint64_t src_bytes, comp_bytes, errors, entries; double elapsed;
+} wjob_t;
+
+static void* wrun(void* arg)
+{
+    wjob_t* j = (wjob_t*)arg;
+    zpack_compress_options opt; opt.method = (zpack_compression_method)j->method; opt.level = j->level;
+    double t0 = now();
+    do {
+        zpack_writer w; memset(&w, 0, sizeof(w));
+        if (zpack_init_writer_heap(&w, 0)) { j->errors++; break; }
+        zpack_write_header(&w); zpack_write_data_header(&w);
+        for (uint64_t i = j->lo; i < j->hi; i++) {
+            zpack_file f; memset(&f, 0, sizeof(f));
+            f.filename = (char*)"e"; f.buffer = j->plain + i * j->entry_size; f.size = j->entry_size; f.options = &opt; f.cctx = NULL;
+            size_t before = w.write_offset;
+            if (zpack_write_files(&w, &f, 1)) j->errors++;
+            j->src_bytes += j->entry_size; j->comp_bytes += w.write_offset - before; j->entries++;
+            if (now() - t0 >= j->seconds && j->entries >= 2) break;
+        }
+        zpack_close_writer(&w);
+    } while (now() - t0 < j->seconds);
+    j->elapsed = now() - t0;
+    return NULL;
+}
+
+/* compress entries [0, count) of `plain` (count x entry_size bytes) with `threads` threads for at least `seconds`;
+ * out[0] = source bytes compressed, out[1] = wall seconds, out[2] = errors, out[3] = compressed bytes produced */
+int ref_baseline_encode(uint8_t* plain, uint64_t entry_size, uint64_t count, int method, int level, int threads, double seconds, double* out)
+{
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > count && count) threads = (int)count;
+    wjob_t* jobs = (wjob_t*)calloc((size_t)threads, sizeof(wjob_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    double t0 = now();
+    for (int t = 0; t < threads; t++) {
+        jobs[t].plain = plain; jobs[t].entry_size = entry_size; jobs[t].method = method; jobs[t].level = level; jobs[t].seconds = seconds;
+        jobs[t].lo = count * (uint64_t)t / (uint64_t)threads;
+        jobs[t].hi = count * (uint64_t)(t + 1) / (uint64_t)threads;
+        pthread_create(&th[t], NULL, wrun, &jobs[t]);
+    }
+    double sb = 0, cb = 0, er = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); sb += (double)jobs[t].src_bytes; cb += (double)jobs[t].comp_bytes; er += (double)jobs[t].errors; }
+    out[0] = sb; out[1] = now() - t0; out[2] = er; out[3] = cb;
+    free(jobs); free(th);
+    return 0;
+}

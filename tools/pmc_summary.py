@@ -43,6 +43,10 @@ if __name__ == "__main__":
             doc["entries_per_gpu"] = int(sys.argv[sys.argv.index("--entries") + 1])
         if "--workload" in sys.argv:
             doc["workload"] = sys.argv[sys.argv.index("--workload") + 1]
+        # identity of the kernel sources the counters were measured on: bench.py quotes the traffic only for this very code
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import csrc_sha1
+        doc["csrc_sha1"] = csrc_sha1()
         with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
             json.dump(doc, fh, indent=1, sort_keys=True)
     for k in sorted(s):

@@ -18,7 +18,7 @@ METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
 DF_GENERAL = 2
 OPT_LZ4_RING = 1
-K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_LZ4_SCAN = 0, 1, 2, 3, 4, 5, 6
+K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_LZ4_SCAN, K_ENCODE = 0, 1, 2, 3, 4, 5, 6, 7
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
 DECODE_DESC = np.dtype([("src_offset", "<u8"), ("comp_size", "<u8"), ("uncomp_size", "<u8"), ("expect_hash", "<u8"),
