@@ -64,6 +64,20 @@ def build_zpack(force=False, verbose=False):
     return ZPACK_SO
 
 
+def build_programs(force=False, verbose=False):
+    """zpack_amd/zpk-batch: the batch-aware `t` / `x` commands over libzpack_amd.so (programs/zpk_batch.c)"""
+    src = os.path.join(HERE, "programs", "zpk_batch.c")
+    exe = os.path.join(HERE, "zpk-batch")
+    if not force and not _newer(exe, [src, ZPACK_SO, os.path.join(ROOT, "include", "zpack.h")]):
+        return exe
+    cmd = ["gcc", "-O2", "-g", "-std=c11", "-Wall", "-Wextra", "-D_FILE_OFFSET_BITS=64", "-I" + os.path.join(ROOT, "include"), "-o", exe, src,
+           "-L" + HERE, "-lzpack_amd", "-lzpk_codec", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return exe
+
+
 def build_helpers():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "benchdata"), "libzpkgen.so"])
@@ -75,6 +89,7 @@ def build_all(force=False, verbose=False):
     build_codec(force, verbose)
     if os.path.isdir(os.path.join(HERE, "host")):
         build_zpack(force, verbose)
+        build_programs(force, verbose)
     build_helpers()
 
 
