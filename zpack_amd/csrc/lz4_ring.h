@@ -70,7 +70,8 @@ __device__ __forceinline__ u64 lx_region(u64 off) { return ((off * 3) >> 4) << 2
 #define LXS_WIN 256u                         // per-lane window of the compressed stream in LDS (measured: 128 B windows = 17 waves per CU run the
                                              // scan 45 % SLOWER — the wave-wide refills, one memory round trip each, set the pace, not occupancy)
 #endif
-#define LXS_STRIDE (LXS_WIN + 16u)           // 16-byte aligned slots
+#define LXS_NCH (LXS_WIN / 16u)                // chunks of the ring (a power of two)
+#define LXS_STRIDE (LXS_WIN + 16u)           // 16-byte aligned slots, banks staggered
 struct alignas(16) Lz4ScanShared { u8 win[64 * LXS_STRIDE + 32]; };
 struct Lz4Unit { u64 blk; u32 bsz_seg; u32 entry; };      // block payload offset in src; bsz | segment index << 20; entry index
 
@@ -154,47 +155,76 @@ __device__ inline u32 lz4_frames_wave(const u8* src, u64 read_hi, u64 e_off, u64
 
 // One lane per unit.  Returns false when the lane's unit cannot be listed (malformed token, a literal run / match beyond the friendly
 // limits, list region full): the caller clears the entry's verdict.  All 64 lanes call (lanes without a unit pass bsz = 0).
-__device__ inline bool lz4_scan_units(Lz4ScanShared& sh, const u8* src, u64 read_hi, u64 blk, u32 bsz, u32 seg, u8* tok, int lane)
+__device__ inline bool lz4_scan_units(Lz4ScanShared& sh, const u8* src, u64 read_hi, u64 blk, u32 bsz, u32 seg, u8* tok, int lane, u64* sdbg = nullptr)
 {
+#ifdef LX_STATS
+    u64 st_ev = 0, st_t0 = __builtin_amdgcn_s_memtime(); u32 st_nev = 0, st_again = 0, st_steps = 0, st_special = 0;
+#endif
+    (void)sdbg;
     const u32 seg_lo = seg * LX_SEG, seg_hi = lx_seg_hi(bsz, seg);
     u64 w = lx_sublist(blk + seg_lo);
     const u64 wend = lx_sublist(blk + seg_hi);
     const u64 cw = w;                          // header: [u32 count][u32 exit]; positions follow; [u32 patch count][u32 valid from] end the region
     w += 8;
-    bool ok = bsz != 0 && w + 8 <= wend && read_hi >= blk + LXS_WIN;
+    // the lane's window: a ring of LXS_NCH 16-byte chunks of the block's byte stream, chunk c (bytes [16c, 16c + 16)) in ring slot
+    // c mod LXS_NCH, i.e. byte x at slot[x mod LXS_WIN]; chunks [lo, hi) are in the ring, chunks [hi, hi + npend) are IN FLIGHT in
+    // registers.  Refills are events for the whole wave (lanes run in lockstep: a private refill would stall all 64 on every step):
+    // when any lane is about to run dry, every lane stores the chunks that arrived since the last event and asks for as many new
+    // ones as its ring has room for — so a load has a whole event interval (~15 steps) to land and nobody waits for memory.
+    const u64 max_chunk = read_hi > blk ? (read_hi - blk) >> 4 : 0;            // 16-byte loads stay inside the source
+    bool ok = bsz != 0 && w + 8 <= wend && ((u64)bsz + 15) >> 4 <= max_chunk;
     u32 exit_pos = bsz;
-    const u32 max_wpos = ok ? (read_hi - blk - LXS_WIN > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)(read_hi - blk - LXS_WIN)) : 0u;
     bool live = ok;
     u32 p = seg_lo > LX_RUNIN ? seg_lo - LX_RUNIN : 0u;        // (segment 0, or a run-in that reaches position 0, is the true chain)
-    u32 wpos = 0, n = 0;
+    u32 n = 0;
     const lds_p8 slot = to_lds_rw(sh.win) + LXS_STRIDE * (u32)lane;
-    bool fill = true;
+    u32 lo = p >> 4, hi = lo, npend = 0;
+    u128 pend[LXS_NCH];
+    #pragma unroll
+    for (u32 k = 0; k < LXS_NCH; k++) { pend[k].lo = 0; pend[k].hi = 0; }
+    const u8* const sb = src + blk;
     for (u32 step = 0;; step++) {
         if (__ballot(live) == 0) break;
         if (step > 70000u) { ok = false; break; }                              // cannot happen: every step consumes input
-        if (__ballot(live && fill) != 0) {                                      // refill all windows together: lanes run in lockstep
+        // ---- refill event: some lane has less than two chunks ahead of it ----
+#ifdef LX_STATS
+        const u64 st_e0 = __builtin_amdgcn_s_memtime(); st_steps++;
+#endif
+        for (int again = 0; again < 2; again++) {
+            const u32 cur = p >> 4;
+            if (__ballot(live && (cur + 2 > hi || cur < lo)) == 0) break;
+#ifdef LX_STATS
+            st_nev++; st_again += again;
+#endif
             if (live) {
-                wpos = p < max_wpos ? p : max_wpos;                             // the window never reaches past the readable source
-                const u8* g = src + blk + wpos;
-                u128 v[LXS_WIN / 16];
                 #pragma unroll
-                for (u32 c = 0; c < LXS_WIN / 16; c++) v[c] = ld128(g + 16 * c);          // all loads in flight, then the stores
+                for (u32 k = 0; k < LXS_NCH; k++) if (k < npend) lds_st128(slot + (((hi + k) & (LXS_NCH - 1)) << 4), pend[k]);   // what has arrived
+                hi += npend; npend = 0;
+                if (hi - lo > LXS_NCH) lo = hi - LXS_NCH;
+                if (cur >= hi || cur < lo) { lo = cur; hi = cur; }              // a jump past everything loaded: start over at the lane's chunk
+                if (lo < cur) lo = cur;                                         // chunks behind the lane are dead
+                u32 room = LXS_NCH - (hi - lo);
+                const u32 left = (bsz + 15) / 16 > hi ? (bsz + 15) / 16 - hi : 0u;
+                if (room > left) room = left;
                 #pragma unroll
-                for (u32 c = 0; c < LXS_WIN / 16; c++) lds_st128(slot + 16 * c, v[c]);
+                for (u32 k = 0; k < LXS_NCH; k++) if (k < room) pend[k] = ld128(sb + 16ull * (hi + k));
+                npend = room;
             }
             wave_mem_fence();
+            // (second pass only for a lane that is STILL dry — it jumped, or the wave has just started: its loads are waited for at once)
         }
+#ifdef LX_STATS
+        st_ev += __builtin_amdgcn_s_memtime() - st_e0;
+#endif
         // ---- one token per live lane.  The common shapes (at most one extension byte per length, everything inside the window and
         // the block) run straight-line: the loop is executed ~1.3 k times by ~8 k waves, every instruction in it counts ----
-        const u32 a = live ? p - wpos : 0u;                                    // <= LXS_WIN - 4 after the refill check
-        const u32 t = lds_ld8((lds_cp8)(slot + a));
-        const u32 e1 = lds_ld8((lds_cp8)(slot + a + 1));
+        const u32 t = lds_ld8((lds_cp8)(slot + (p & (LXS_WIN - 1))));
+        const u32 e1 = lds_ld8((lds_cp8)(slot + ((p + 1) & (LXS_WIN - 1))));
         const bool lx = (t >> 4) == 15;
         u32 lit = (t >> 4) + (lx ? e1 : 0u);
         const u32 mo = p + 1 + (lx ? 1u : 0u) + lit;                           // offset field
-        const u32 a2 = mo + 2 - wpos;
-        const bool far = a2 >= LXS_WIN;                                        // the match-length byte lies beyond the window
-        const u32 e2 = lds_ld8((lds_cp8)(slot + (far ? 0u : a2)));
+        const bool far = ((mo + 2) >> 4) >= hi;                                // the match-length byte is not in the ring
+        const u32 e2 = lds_ld8((lds_cp8)(slot + ((mo + 2) & (LXS_WIN - 1))));
         const u32 mlc = t & 15;
         const bool mx = mlc == 15;
         u32 nxt = mo + 2 + (mx ? 1u : 0u);
@@ -202,6 +232,9 @@ __device__ inline bool lz4_scan_units(Lz4ScanShared& sh, const u8* src, u64 read
         bool reject = mo > bsz || (!last && (bsz - mo < 2 || nxt >= bsz));
         const bool special = (lx && e1 == 255) || (mx && !last && (far || e2 == 255)) || reject;
         if (__ballot(live && special) != 0) {                                  // rare: long extension chains, malformed tokens, run-in misses
+#ifdef LX_STATS
+            st_special++;
+#endif
             if (live && special) {
                 const u8* b = src + blk;
                 bool bad = false;
@@ -236,9 +269,11 @@ __device__ inline bool lz4_scan_units(Lz4ScanShared& sh, const u8* src, u64 read
             exit_pos = leave ? nxt : exit_pos;                                 // (a chain that ENDS inside the unit keeps exit = bsz)
             p = miss ? p + 1 : (good && !last ? nxt : p);
             live = live && !fail && !full && !(good && last) && !leave;
-            fill = p - wpos > LXS_WIN - 4u;
         }
     }
+#ifdef LX_STATS
+    if (sdbg && lane == 0) { sdbg[0] = __builtin_amdgcn_s_memtime() - st_t0; sdbg[1] = st_ev; sdbg[2] = st_nev; sdbg[3] = st_again; sdbg[4] = st_steps; sdbg[5] = st_special; }
+#endif
     if (ok) {
         { st32(tok + cw, n); st32(tok + cw + 4, exit_pos); st32(tok + wend - 8, 0u); st32(tok + wend - 4, 0u); }
     }
@@ -811,7 +846,9 @@ __device__ inline LxResult lz4f_exec_wave(Lz4ExecShared& sh, const u8* src, cons
         R.hash = xxh3_64_wave(dst, uncomp_size, lane);
     }
 #ifdef LX_STATS
+#ifndef LX_STATS_SCAN_ONLY
     if (lx_dbg && lane == 0) { for (int k = 0; k < 12; k++) lx_dbg[k] = O.tm[k]; lx_dbg[12] = __builtin_amdgcn_s_memtime() - t_begin; }
+#endif
 #endif
     R.rc = LX_OK;
     return R;

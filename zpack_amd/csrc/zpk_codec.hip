@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void k_lz4_frames(const u8* __restrict__ src, c
 
 // ... token scan, one LANE per unit (one LX_SEG-byte segment of one compressed block) ...
 __global__ __launch_bounds__(64) void k_lz4_scan(const u8* __restrict__ src, const u8* read_hi, const u32* __restrict__ counters,
-                                                 const Lz4Unit* __restrict__ units, u8* __restrict__ tok, u32* __restrict__ meta)
+                                                 const Lz4Unit* __restrict__ units, u8* __restrict__ tok, u32* __restrict__ meta, u64* __restrict__ dbg)
 {
     const int lane = lane_id();
     __shared__ Lz4ScanShared shs;
@@ -228,7 +228,8 @@ __global__ __launch_bounds__(64) void k_lz4_scan(const u8* __restrict__ src, con
     if ((u64)blockIdx.x * blockDim.x >= nu) return;
     Lz4Unit u; u.blk = 0; u.bsz_seg = 0; u.entry = 0;
     if (idx < nu) u = units[idx];
-    const bool ok = lz4_scan_units(shs, src, (u64)(read_hi - src), u.blk, u.bsz_seg & 0xFFFFFu, u.bsz_seg >> 20, tok, lane);
+    const bool ok = lz4_scan_units(shs, src, (u64)(read_hi - src), u.blk, u.bsz_seg & 0xFFFFFu, u.bsz_seg >> 20, tok, lane,
+                                   dbg && blockIdx.x < 1024 ? dbg + 8 * blockIdx.x : nullptr);
     if (idx < nu && !ok) meta[u.entry] = 2u;                  // not listed: a unit of it could not be
 }
 
@@ -618,7 +619,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
         hipLaunchKernelGGL(k_lz4_frames, dim3((u32)((n + 63) / 64)), dim3(64), 0, st, src, read_lo, read_hi, desc,
                            c->d_lists + L_LZ4 * stride, c->d_counters, c->d_lz4meta, (Lz4Unit*)c->d_units, (u32)unit_cap);
         hipLaunchKernelGGL(k_lz4_scan, dim3((u32)((unit_cap + 63) / 64)), dim3(64), 0, st, src, read_hi, c->d_counters,
-                           (const Lz4Unit*)c->d_units, c->d_tok, c->d_lz4meta);
+                           (const Lz4Unit*)c->d_units, c->d_tok, c->d_lz4meta, c->d_dbg);
         hipLaunchKernelGGL(k_lz4_seam, dim3((u32)((unit_cap + 63) / 64)), dim3(64), 0, st, src, c->d_counters,
                            (const Lz4Unit*)c->d_units, c->d_tok, c->d_lz4meta);
     }
