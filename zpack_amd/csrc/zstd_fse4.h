@@ -112,12 +112,23 @@ __device__ __forceinline__ void zf_ring_put(lds_p8 ring, i32 chunk, int sub, u12
     lds_st128(ring + slot + 16u * (u32)sub, v);
     if (slot == 0 && sub == 0) lds_st64(ring + ZF_RING, v.lo);
 }
+// 32 stream bits starting at bit `bit`, out of the ring: TWO ALIGNED dword reads + one v_alignbit.  (The one 8-byte read at any byte
+// offset this replaces was the kernel's bottleneck: rocprofv3 round 2, SQ_LDS_UNALIGNED_STALL 2.9e9 + SQ_LDS_IDX_ACTIVE 3.9e9 of 6.9e9
+// CU-cycles — an LDS access that is not naturally aligned costs ~26 extra LDS cycles on gfx950.)
+__device__ __forceinline__ u32 zf_ring_bits(lds_cp8 ring, i32 bit)
+{
+    const u32 byte = (u32)(bit >> 3) & (ZF_RING - 1u);
+#ifdef ZF_OLD_RING_READ
+    return (u32)(((const ZPK_LDS pk64*)(ring + byte))->v >> (bit & 7));
+#endif
+    const ZPK_LDS u32* w = (const ZPK_LDS u32*)(ring + (byte & ~3u));          // the 8-byte mirror behind the ring covers w[1] at the wrap
+    const u32 d0 = w[0], d1 = w[1];
+    return __builtin_amdgcn_alignbit(d1, d0, ((byte & 3u) << 3) | ((u32)bit & 7u));
+}
 // n (<= 31) stream bits starting at bit `bit` (may be negative: zeros), out of the ring
 __device__ __forceinline__ u32 zf_bits(lds_cp8 ring, i32 bit, u32 n)
 {
-    const u32 idx = (u32)(bit >> 3) & (ZF_RING - 1u);
-    const u64 v = ((const ZPK_LDS pk64*)(ring + idx))->v;
-    return (u32)(v >> (bit & 7)) & ((1u << n) - 1u);
+    return zf_ring_bits(ring, bit) & ((1u << n) - 1u);
 }
 __device__ __forceinline__ u32 lds_ld32u(lds_cp8 p) { return ((const ZPK_LDS pk32*)p)->v; }
 
@@ -465,8 +476,7 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                 const u32 total = (u32)__builtin_amdgcn_ds_swizzle((int)s, 0xF0);       // lane 7 of the row -> all 16 lanes
                 const u32 base = symt[zf_sym(cell)];
                 const i32 b = pos - (i32)s;
-                const u64 w = ((const ZPK_LDS pk64*)(ring + ((u32)(b >> 3) & (ZF_RING - 1u))))->v;
-                const u32 bits = (u32)(w >> (b & 7)) & ((1u << n) - 1u);
+                const u32 bits = zf_ring_bits((lds_cp8)ring, b) & ((1u << n) - 1u);
                 const u32 nst = zf_next(cell) + bits;                // lanes 5..7: next state (libzstd updates after the last sequence too)
                 // lanes 0..3 take the mirrored lane's state (bank 0 of the row), lanes 4..7 keep their own
                 const u32 idx = (u32)__builtin_amdgcn_update_dpp((int)nst, (int)nst, 0x141, 0xf, 0x5, false);
