@@ -253,3 +253,24 @@ def test_encoder_stress_alphabets_and_boundaries(Z, method, level):
         if name.startswith("geom") or name.startswith("const") or name.startswith("period"):
             assert ents[name]["comp_size"] < 0.8 * len(data), (name, ents[name]["comp_size"])
         assert ents[name]["comp_size"] <= len(data) + len(data) // 200 + 64, (name, ents[name]["comp_size"])
+
+
+@pytest.mark.parametrize("method", [METHOD_LZ4, METHOD_ZSTD])
+def test_compression_level_is_honoured(Z, method):
+    """zpack_compress_options.level reaches the codec (the reference hands it to ZSTD_compressCCtx / LZ4F preferences,
+    lib/zpack_write.c:179,199-201): more effort never makes the archive larger on compressible data and makes it smaller somewhere,
+    and every level's archive decodes bit-exactly with the oracle and with stock liblz4 / libzstd (the compiled reference)."""
+    want = [("t%d" % i, dg.fill(dg.TEXT, 51, i, 300000).tobytes()) for i in range(3)] + \
+           [("r%d" % i, dg.fill(dg.RECORDS, 51, i, 300000).tobytes()) for i in range(3)] + \
+           [("u%d" % i, dg.fill(dg.RUNS, 51, i, 100000).tobytes()) for i in range(2)]
+    sizes = {}
+    for level in (1, 3, 9):
+        arc = Z.write_archive(want, method, level)
+        _decode_all_with_checkers(arc, want)
+        sizes[level] = {e["filename"]: e["comp_size"] for e in zpk.parse(arc)}
+    tot = {l: sum(v.values()) for l, v in sizes.items()}
+    assert tot[3] < tot[1] and tot[9] < tot[3], tot
+    for name in sizes[1]:
+        if name[0] in "tr":
+            assert sizes[9][name] <= sizes[3][name] * 1.002 and sizes[3][name] <= sizes[1][name] * 1.002, (name, [sizes[l][name] for l in (1, 3, 9)])
+    print("method %d: total compressed bytes by level %s" % (method, tot))
