@@ -83,6 +83,8 @@ def build_helpers():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "benchdata"), "libzpkgen.so"])
     if os.path.isdir("/root/reference/lib"):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+        if os.path.exists(CODEC_SO):         # INTEGRATION.md section B applied to a scratch copy of the reference, linked to the product codec
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "patched"])
 
 
 def build_all(force=False, verbose=False):
