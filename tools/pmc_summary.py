@@ -24,7 +24,10 @@ def summarise(d):
     for k, cs in acc.items():
         out[k] = {}
         for c, v in cs.items():
-            # the first dispatches are warm-up launches; all launches of a kernel do the same work here
+            # all FULL launches of a kernel do the same work; bench.py also launches the kernels on its small copy-ceiling batch (and
+            # on batches that hold no entry of the kernel's method): those dispatches, far below the largest, are left out of the mean
+            top = max(v)
+            v = [x for x in v if x >= 0.5 * top] if top > 0 else v
             m = sum(v) / len(v)
             if c in ("FETCH_SIZE", "WRITE_SIZE"):
                 m *= 1024.0

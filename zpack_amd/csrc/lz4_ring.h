@@ -463,6 +463,257 @@ __device__ inline int lx_append_raw(LxOut& O, const u8* s, u64 n, const u8* read
     return LX_OK;
 }
 
+// `n` copies of one byte appended to the output (Zstandard RLE blocks / RLE literals)
+__device__ inline int lx_append_fill(LxOut& O, u32 byte, u64 n, u64 dst_cap, int lane)
+{
+    if ((u64)O.wp + n > dst_cap) return LX_E_CAPACITY;
+    u128 pat; pat.lo = 0x0101010101010101ull * (u64)(byte & 0xFFu); pat.hi = pat.lo;
+    while (n) {
+        const u32 m = n < 1024u ? (u32)n : 1024u;
+        if (O.wp + m > O.rb + LX_RING) lx_slide(O, lane);
+        const u32 c = 16u * (u32)lane;
+        lds_or_piece(O.ring, (O.wp - O.rb) + (c < m ? c : 0u), pat, c < m ? (m - c < 16u ? m - c : 16u) : 0u);
+        wave_mem_fence();
+        O.wp += m; n -= m;
+        lx_flush_blocks(O, lane);
+    }
+    return LX_OK;
+}
+
+// a match of ANY length appended to the output: out[i] = out[i - off].  Everything from (match start - off) on is periodic with period
+// off, so every step copies from the largest multiple of off that is already there (<= 1 KiB): the step size doubles until it is 1 KiB
+__device__ inline int lx_append_match(LxOut& O, u32 off, u64 n, u32 hist_lo, u64 dst_cap, int lane)
+{
+    if (off == 0 || off > O.wp - hist_lo) return LX_E_OFFSET;
+    if ((u64)O.wp + n > dst_cap) return LX_E_CAPACITY;
+    u64 done = 0;
+    while (n) {
+        u32 m, D;
+        if (off >= 1024u) { D = off; m = n < 1024u ? (u32)n : 1024u; }
+        else {
+            const u64 avail = (u64)off + done;                                   // periodic bytes behind the write position
+            const u32 cap = avail < 1024u ? (u32)avail : 1024u;
+            D = cap / off * off;                                                 // >= off
+            m = n < D ? (u32)n : D;
+        }
+        if (O.wp + m > O.rb + LX_RING) lx_slide(O, lane);
+        const u32 s = O.wp - D;
+        if (m >= 16u) {
+            const u32 c = 16u * (u32)lane;
+            if (c < m) {
+                const u32 oc = c + 16u <= m ? c : m - 16u;                        // the last chunk overlaps the one before: same bytes twice
+                lds_or_piece(O.ring, (O.wp - O.rb) + oc, lx_load16(O, s + oc), 16u);
+            }
+        } else if (lane == 0) lds_or_piece(O.ring, O.wp - O.rb, lx_load16(O, s), m);
+        wave_mem_fence();
+        O.wp += m; n -= m; done += m;
+        lx_flush_blocks(O, lane);
+    }
+    return LX_OK;
+}
+
+// literals that lie in memory (Zstandard: the block's raw literals, or the Huffman-decoded ones in the workgroup's scratch)
+struct LxLitGlobal {
+    const u8* p; const u8* rd_hi;
+    __device__ __forceinline__ u128 load16(u32 oc) const
+    {
+        const u8* g = p + oc;
+        if (g + 16 <= rd_hi) return ld128(g);
+        u128 v; v.lo = 0; v.hi = 0;
+        for (u32 i = 0; i < 16 && g + i < rd_hi; i++) { const u64 b = (u64)ld8(g + i) << (8 * (i & 7)); if (i < 8) v.lo |= b; else v.hi |= b; }
+        return v;
+    }
+};
+// literals that are all one byte (Zstandard RLE literals)
+struct LxLitFill {
+    u32 byte;
+    __device__ __forceinline__ u128 load16(u32) const { u128 v; v.lo = 0x0101010101010101ull * (u64)(byte & 0xFFu); v.hi = v.lo; return v; }
+};
+
+// literal source of a batch lane: LZ4 reads its literals out of the LDS stage of the compressed span
+struct LxLitStage {
+    lds_cp8 S; u32 lit_a;
+    __device__ __forceinline__ u128 load16(u32 oc) const { return lds_ld16_any(S, lit_a + oc); }
+};
+
+// Execute `cnt` sequences (lane k < cnt: literal length ll from L, then a match of ml bytes at distance off; ml = 0: none) at the
+// ring's write position: output positions (prefix sum), in-batch dependencies, literals and matches OR-ed into the ring, whole
+// 1 KiB blocks flushed (and hashed).  cnt may come back SMALLER: a batch whose output does not fit the ring is cut (the caller goes
+// on behind the sequences taken).  Lengths must be <= LX_MAX_LL / LX_MAX_ML.  hist_lo = lowest abs output position a match may reach.
+template <class LitSrc>
+__device__ __forceinline__ int lx_exec_batch(LxOut& O, u32& cnt, u32 ll, u32 ml, u32 off, const LitSrc& L, u32 hist_lo, u64 dst_cap,
+                                             int lane, SeqStats& stt)
+{
+    bool act = (u32)lane < cnt;
+    if (!act) { ll = 0; ml = 0; }
+    // ---- output positions ----
+    u32 x = wave_scan_add(ll + ml);
+    u32 total = (u32)__builtin_amdgcn_readlane((int)x, 63);
+    if (O.wp + total > O.rb + LX_RING) {                 // (only a batch of more than 2 KiB of output gets here)
+        lx_slide(O, lane);
+        const u32 free_ = O.rb + LX_RING - O.wp;
+        if (total > free_) {                         // take the sequences that fit; the rest next time round
+            const u32 c2 = (u32)__popcll(__ballot(act && x <= free_));
+            if (c2 == 0) return LX_E_FIT;
+            cnt = c2; act = (u32)lane < cnt;
+            if (!act) { ll = 0; ml = 0; }
+            x = wave_scan_add(ll + ml);
+            total = (u32)__builtin_amdgcn_readlane((int)x, 63);
+        }
+    }
+    if ((u64)O.wp + total > dst_cap) return LX_E_CAPACITY;
+    const u32 o = O.wp + (x - ll - ml);              // abs position of this sequence's literals
+    const u32 ms = o + ll;                           //               ... of its match
+    const bool has_match = act && ml != 0;
+    if (__ballot(has_match && (off == 0 || off > ms - hist_lo)) != 0) return LX_E_OFFSET;
+    LXT(3);
+    // ---- in-batch dependencies (positions relative to wp) ----
+    u64 pending = __ballot(has_match);
+    const u32 r_ms = ms - O.wp, r_me = r_ms + ml;
+    const u32 need_len = ml < off ? ml : off;
+    i64 srel;
+    u64 need = 0;
+    {
+        // Few lanes read this batch's own output on text (1-2 of 64): for those, one sweep per reader — its source range is
+        // broadcast, every earlier lane answers with one compare, the ballot is the reader's dependency set — costs a dozen
+        // plain instructions; the sorted search + pointer jumping of seq_dependencies (a dozen dependent LDS round trips)
+        // is for batches where most lanes do (records: every match reads the record before it).
+        const i32 s0 = (i32)r_ms - (i32)off;
+        const u64 rd = __ballot(has_match && s0 + (i32)need_len > 0);
+        if (__popcll(rd) <= 6) {
+            srel = s0;
+            u64 m = rd;
+            while (m) {
+                const int k = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const i32 ks = __builtin_amdgcn_readlane(s0, k);
+                const i32 ke = ks + (i32)__builtin_amdgcn_readlane((int)need_len, k);
+                const u64 ov = __ballot(has_match && lane < k && (i32)r_me > ks && (i32)r_ms < ke);
+                if (lane == k) need = ov;
+            }
+        } else need = seq_dependencies<i32>(has_match, r_ms, r_me, off, need_len, pending, lane, srel, stt);
+    }
+    const u32 sabs = (u32)((i64)O.wp + srel);        // abs position of the (possibly re-pointed) source
+    const bool overlap = ml > need_len;              // offset < length: the match feeds itself
+    const bool early = has_match && !overlap && srel + (i64)need_len <= 0;
+    const lds_p8 ring = O.ring;
+    LXT(4);
+    // ---- literals: stage -> ring ----
+#ifndef LX_ABL_NOLIT
+    {
+        // every lane: its first 16 literal bytes (or fewer); the few longer runs go on in 16-byte steps, the last one overlapped
+        lds_or_piece(ring, o - O.rb, L.load16(0u), ll < 16 ? ll : 16u);
+        u64 bm = __ballot(ll > 16);
+        for (u32 c = 16; bm; c += 16) {
+            const bool on = c < ll;
+            const u32 oc = !on ? 0u : (c + 16 <= ll ? c : ll - 16);
+            lds_or_piece(ring, o - O.rb + oc, L.load16(oc), on ? 16u : 0u);
+            bm = __ballot(c + 16 < ll);
+        }
+    }
+#endif
+    LXT(5);
+    // ---- matches whose whole source is older than this batch ----
+#ifndef LX_ABL_NOMATCH
+    {
+        u128 v; v.lo = 0; v.hi = 0;
+        if (early) v = lx_load16(O, sabs);
+        lds_or_piece(ring, ms - O.rb, v, !early ? 0u : (ml < 16 ? ml : 16u));
+        u64 bm = __ballot(early && ml > 16);
+        for (u32 c = 16; bm; c += 16) {
+            const bool on = early && c < ml;
+            const u32 oc = !on ? 0u : (c + 16 <= ml ? c : ml - 16);
+            u128 vv; vv.lo = 0; vv.hi = 0;
+            if (on) vv = lx_load16(O, sabs + oc);
+            lds_or_piece(ring, ms - O.rb + oc, vv, on ? 16u : 0u);
+            bm = __ballot(early && c + 16 < ml);
+        }
+    }
+#endif
+    wave_mem_fence();
+    LXT(6);
+    // ---- rounds: matches that read this batch's own output ----
+    u64 done = ~pending | __ballot(early);
+    pending &= ~done;
+    u32 guard = 0;
+    while (pending) {
+        const bool ready = has_match && ((pending >> lane) & 1) && (need & ~done) == 0;
+        const u64 rmask = __ballot(ready);
+        if (rmask == 0 || ++guard > 70) return LX_E_ROUNDS;
+        if (ready && !overlap) {
+            for (u32 c = 0; c < ml; c += 16) {
+                const u32 oc = c + 16 <= ml || ml < 16 ? c : ml - 16;
+                lds_or_piece(ring, ms - O.rb + oc, lx_load16(O, sabs + oc), ml < 16 ? ml : 16u);
+            }
+        }
+        u64 cm = __ballot(ready && overlap);
+        while (cm) {                                 // self-overlapping matches, one at a time, whole wave; source and target are in the ring
+            const int k = __ffsll((long long)cm) - 1;
+            cm &= cm - 1;
+            const u32 n = (u32)__builtin_amdgcn_readlane((int)ml, k);
+            const u32 ko = (u32)__builtin_amdgcn_readlane((int)off, k);
+            const u32 D = (u32)__builtin_amdgcn_readlane((int)ms, k) - O.rb;
+            wave_mem_fence();
+            if (ko < 16) {
+                for (u32 c = (u32)lane; c < n; c += 64) lds_st8(ring + D + c, (u8)lds_ld8((lds_cp8)(ring + D - ko + c % ko)));
+            } else {
+                for (u32 base = 0; base < n; base += ko) {       // period by period: no lane reads what the same round writes
+                    const u32 m = n - base < ko ? n - base : ko;
+                    if (m >= 16) {
+                        for (u32 c = 16u * (u32)lane; c < m; c += 1024u) {
+                            const u32 oc = c + 16 <= m ? c : m - 16;
+                            lds_or_piece(ring, D + base + oc, lds_ld16_any((lds_cp8)ring, D + base - ko + oc), 16u);
+                        }
+                    } else if (lane == 0) lds_or_piece(ring, D + base, lds_ld16_any((lds_cp8)ring, D + base - ko), m);
+                    wave_mem_fence();
+                }
+            }
+            wave_mem_fence();
+        }
+        wave_mem_fence();
+        done |= rmask;
+        pending &= ~rmask;
+    }
+    LXT(7);
+    O.wp += total;
+    lx_flush_blocks(O, lane);
+    return LX_OK;
+}
+
+struct LxResult { int rc; u64 produced; u64 hash; };
+
+// init / finish of an entry's ring
+__device__ __forceinline__ void lx_begin(LxOut& O, lds_p8 ring, u8* dst, u64 uncomp_size, int lane)
+{
+    O.ring = ring; O.dst = dst;
+    for (u32 c = 16u * (u32)lane; c < LX_RING + 32u; c += 1024u) { u128 z; z.lo = 0; z.hi = 0; lds_st128(O.ring + c, z); }     // ring bytes >= wp are zero, always
+    wave_mem_fence();
+    O.wp = 0; O.rb = 0; O.fp = 0;
+    O.hash_blocks = uncomp_size > 240 ? (u32)((uncomp_size - 1) >> 10) : 0u;
+    O.xs.init(lane);
+}
+// the tail (what is left of the last 1 KiB block, exact to the byte), then XXH3 of dst[0, uncomp_size) (lib/zpack_read.c:466): fused
+// when the entry produced exactly that many bytes, by re-reading otherwise
+__device__ __forceinline__ void lx_finish(LxOut& O, u8* dst, u64 uncomp_size, LxResult& R, int lane)
+{
+    lx_flush_blocks(O, lane);
+    {
+        const u32 tail = O.wp - O.fp, c = 16u * (u32)lane;
+        if (c < tail) {
+            const u128 v = lds_ld128((lds_cp8)(O.ring + (O.fp - O.rb) + c));
+            if (c + 16 <= tail) st128(dst + O.fp + c, v);
+            else gstore_upto16(dst + O.fp + c, v, tail - c);
+        }
+    }
+    wave_mem_fence();
+    R.produced = O.wp;
+    if (uncomp_size > 240 && R.produced == uncomp_size) {
+        const u64 nb = O.hash_blocks;
+        const u32 nstripes = (u32)(((uncomp_size - 1) - (nb << 10)) >> 6);
+        R.hash = uni64(O.xs.finish(dst + (nb << 10), nstripes, dst + uncomp_size, uncomp_size, lane));
+    } else R.hash = xxh3_64_wave(dst, uncomp_size, lane);
+}
+
 // One sub-list of a compressed block: `nseq` listed tokens at lst[] (positions >= min_pos), block bytes blk[0, C); the last of them must
 // end exactly at end_pos (where the next sub-list's first token starts; C and `final` for the block's last sub-list, whose last sequence
 // is the literal-only one).  hist_lo = lowest abs output position a match may reach, block_out = where the block's output began.
@@ -584,138 +835,13 @@ __device__ inline int lx_block(Lz4ExecShared& sh, LxOut& O, const u8* blk, u32 C
         // the list verifies: every token ends where the next one starts (the last one at the end of the block), lengths in range
         if (__ballot(act && (seq_end != Nx - p_first || ll > LX_MAX_LL || ml > LX_MAX_ML)) != 0) return LX_E_TOKEN;
         LXT(2);
-        // ---- output positions ----
-        u32 x = wave_scan_add(ll + ml);
-        u32 total = (u32)__builtin_amdgcn_readlane((int)x, 63);
-        if (O.wp + total > O.rb + LX_RING) {                 // (only a batch of more than 2 KiB of output gets here)
-            lx_slide(O, lane);
-            const u32 free_ = O.rb + LX_RING - O.wp;
-            if (total > free_) {                         // take the sequences that fit; the rest next time round
-                const u32 c2 = (u32)__popcll(__ballot(act && x <= free_));
-                if (c2 == 0) return LX_E_FIT;
-                cnt = c2; act = (u32)lane < cnt;
-                if (!act) { ll = 0; ml = 0; }
-                x = wave_scan_add(ll + ml);
-                total = (u32)__builtin_amdgcn_readlane((int)x, 63);
-            }
-        }
-        if ((u64)O.wp + total > dst_cap) return LX_E_CAPACITY;
-        if (O.wp + total - block_out > 65536u) return LX_E_BLOCKMAX;
-        const u32 o = O.wp + (x - ll - ml);              // abs position of this sequence's literals
-        const u32 ms = o + ll;                           //               ... of its match
-        const bool has_match = act && ml != 0;
-        if (__ballot(has_match && (off == 0 || off > ms - hist_lo)) != 0) return LX_E_OFFSET;
-        LXT(3);
-        // ---- in-batch dependencies (positions relative to wp) ----
-        u64 pending = __ballot(has_match);
-        const u32 r_ms = ms - O.wp, r_me = r_ms + ml;
-        const u32 need_len = ml < off ? ml : off;
-        i64 srel;
-        u64 need = 0;
+        // ---- execute: output positions, dependencies, copies into the ring, flush (lx_exec_batch) ----
         {
-            // Few lanes read this batch's own output on text (1-2 of 64): for those, one sweep per reader — its source range is
-            // broadcast, every earlier lane answers with one compare, the ballot is the reader's dependency set — costs a dozen
-            // plain instructions; the sorted search + pointer jumping of seq_dependencies (a dozen dependent LDS round trips)
-            // is for batches where most lanes do (records: every match reads the record before it).
-            const i32 s0 = (i32)r_ms - (i32)off;
-            const u64 rd = __ballot(has_match && s0 + (i32)need_len > 0);
-            if (__popcll(rd) <= 6) {
-                srel = s0;
-                u64 m = rd;
-                while (m) {
-                    const int k = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const i32 ks = __builtin_amdgcn_readlane(s0, k);
-                    const i32 ke = ks + (i32)__builtin_amdgcn_readlane((int)need_len, k);
-                    const u64 ov = __ballot(has_match && lane < k && (i32)r_me > ks && (i32)r_ms < ke);
-                    if (lane == k) need = ov;
-                }
-            } else need = seq_dependencies<i32>(has_match, r_ms, r_me, off, need_len, pending, lane, srel, stt);
+            const LxLitStage lits = { S, lit_a };
+            const int rcb = lx_exec_batch(O, cnt, ll, ml, off, lits, hist_lo, dst_cap, lane, stt);
+            if (rcb != LX_OK) return rcb;
+            if (O.wp - block_out > 65536u) return LX_E_BLOCKMAX;
         }
-        const u32 sabs = (u32)((i64)O.wp + srel);        // abs position of the (possibly re-pointed) source
-        const bool overlap = ml > need_len;              // offset < length: the match feeds itself
-        const bool early = has_match && !overlap && srel + (i64)need_len <= 0;
-        const lds_p8 ring = O.ring;
-        LXT(4);
-        // ---- literals: stage -> ring ----
-#ifndef LX_ABL_NOLIT
-        {
-            // every lane: its first 16 literal bytes (or fewer); the few longer runs go on in 16-byte steps, the last one overlapped
-            lds_or_piece(ring, o - O.rb, lds_ld16_any(S, lit_a), ll < 16 ? ll : 16u);
-            u64 bm = __ballot(ll > 16);
-            for (u32 c = 16; bm; c += 16) {
-                const bool on = c < ll;
-                const u32 oc = !on ? 0u : (c + 16 <= ll ? c : ll - 16);
-                lds_or_piece(ring, o - O.rb + oc, lds_ld16_any(S, lit_a + oc), on ? 16u : 0u);
-                bm = __ballot(c + 16 < ll);
-            }
-        }
-#endif
-        LXT(5);
-        // ---- matches whose whole source is older than this batch ----
-#ifndef LX_ABL_NOMATCH
-        {
-            u128 v; v.lo = 0; v.hi = 0;
-            if (early) v = lx_load16(O, sabs);
-            lds_or_piece(ring, ms - O.rb, v, !early ? 0u : (ml < 16 ? ml : 16u));
-            u64 bm = __ballot(early && ml > 16);
-            for (u32 c = 16; bm; c += 16) {
-                const bool on = early && c < ml;
-                const u32 oc = !on ? 0u : (c + 16 <= ml ? c : ml - 16);
-                u128 vv; vv.lo = 0; vv.hi = 0;
-                if (on) vv = lx_load16(O, sabs + oc);
-                lds_or_piece(ring, ms - O.rb + oc, vv, on ? 16u : 0u);
-                bm = __ballot(early && c + 16 < ml);
-            }
-        }
-#endif
-        wave_mem_fence();
-        LXT(6);
-        // ---- rounds: matches that read this batch's own output ----
-        u64 done = ~pending | __ballot(early);
-        pending &= ~done;
-        u32 guard = 0;
-        while (pending) {
-            const bool ready = has_match && ((pending >> lane) & 1) && (need & ~done) == 0;
-            const u64 rmask = __ballot(ready);
-            if (rmask == 0 || ++guard > 70) return LX_E_ROUNDS;
-            if (ready && !overlap) {
-                for (u32 c = 0; c < ml; c += 16) {
-                    const u32 oc = c + 16 <= ml || ml < 16 ? c : ml - 16;
-                    lds_or_piece(ring, ms - O.rb + oc, lx_load16(O, sabs + oc), ml < 16 ? ml : 16u);
-                }
-            }
-            u64 cm = __ballot(ready && overlap);
-            while (cm) {                                 // self-overlapping matches, one at a time, whole wave; source and target are in the ring
-                const int k = __ffsll((long long)cm) - 1;
-                cm &= cm - 1;
-                const u32 n = (u32)__builtin_amdgcn_readlane((int)ml, k);
-                const u32 ko = (u32)__builtin_amdgcn_readlane((int)off, k);
-                const u32 D = (u32)__builtin_amdgcn_readlane((int)ms, k) - O.rb;
-                wave_mem_fence();
-                if (ko < 16) {
-                    for (u32 c = (u32)lane; c < n; c += 64) lds_st8(ring + D + c, (u8)lds_ld8((lds_cp8)(ring + D - ko + c % ko)));
-                } else {
-                    for (u32 base = 0; base < n; base += ko) {       // period by period: no lane reads what the same round writes
-                        const u32 m = n - base < ko ? n - base : ko;
-                        if (m >= 16) {
-                            for (u32 c = 16u * (u32)lane; c < m; c += 1024u) {
-                                const u32 oc = c + 16 <= m ? c : m - 16;
-                                lds_or_piece(ring, D + base + oc, lds_ld16_any((lds_cp8)ring, D + base - ko + oc), 16u);
-                            }
-                        } else if (lane == 0) lds_or_piece(ring, D + base, lds_ld16_any((lds_cp8)ring, D + base - ko), m);
-                        wave_mem_fence();
-                    }
-                }
-                wave_mem_fence();
-            }
-            wave_mem_fence();
-            done |= rmask;
-            pending &= ~rmask;
-        }
-        LXT(7);
-        O.wp += total;
-        lx_flush_blocks(O, lane);
         LXT(8);
         b0 += cnt;
         if (cnt == planned && rhythm && b0 < nseq) {                          // in rhythm: what was "next" is current now
@@ -731,8 +857,6 @@ __device__ inline int lx_block(Lz4ExecShared& sh, LxOut& O, const u8* blk, u32 C
     }
     return LX_OK;
 }
-
-struct LxResult { int rc; u64 produced; u64 hash; };
 
 // whole frame; all arguments uniform.  rc != LX_OK: nothing about the entry is decided (partial output may have been written)
 __device__ inline LxResult lz4f_exec_wave(Lz4ExecShared& sh, const u8* src, const u8* read_hi, u64 e_off, u64 e_size, const u8* tok,
@@ -760,18 +884,12 @@ __device__ inline LxResult lz4f_exec_wave(Lz4ExecShared& sh, const u8* src, cons
     const bool indep = (uld8(ip + 4) >> 5) & 1;
     ip += 7;
     LxOut O;
-    O.ring = to_lds_rw(sh.ring); O.dst = dst;
-    for (u32 c = 16u * (u32)lane; c < LX_RING + 32u; c += 1024u) { u128 z; z.lo = 0; z.hi = 0; lds_st128(O.ring + c, z); }     // ring bytes >= wp are zero, always
-    wave_mem_fence();
-    O.wp = 0; O.rb = 0; O.fp = 0;
+    lx_begin(O, to_lds_rw(sh.ring), dst, uncomp_size, lane);
 #ifdef LX_STATS
     for (int k = 0; k < 12; k++) O.tm[k] = 0;
     O.t_last = __builtin_amdgcn_s_memtime();
     const u64 t_begin = O.t_last;
 #endif
-    const bool fused = uncomp_size > 240;
-    O.hash_blocks = fused ? (u32)((uncomp_size - 1) >> 10) : 0u;
-    O.xs.init(lane);
     for (;;) {
         if (iend - ip < 4) return R;
         const u32 bh = uld32(ip);
@@ -824,27 +942,7 @@ __device__ inline LxResult lz4f_exec_wave(Lz4ExecShared& sh, const u8* src, cons
         ip += bsz;
     }
     if (ip != iend) return R;
-    // ---- the tail: what is left of the last 1 KiB block, exact to the byte ----
-    lx_flush_blocks(O, lane);
-    {
-        const u32 tail = O.wp - O.fp, c = 16u * (u32)lane;
-        if (c < tail) {
-            const u128 v = lds_ld128((lds_cp8)(O.ring + (O.fp - O.rb) + c));
-            if (c + 16 <= tail) st128(dst + O.fp + c, v);
-            else gstore_upto16(dst + O.fp + c, v, tail - c);
-        }
-    }
-    wave_mem_fence();
-    R.produced = O.wp;
-    // ---- XXH3 of dst[0, uncomp_size) (lib/zpack_read.c:466): fused when the frame produced exactly that many bytes ----
-    if (fused && R.produced == uncomp_size) {
-        const u64 nb = O.hash_blocks;
-        const u32 nstripes = (u32)(((uncomp_size - 1) - (nb << 10)) >> 6);
-        R.hash = O.xs.finish(dst + (nb << 10), nstripes, dst + uncomp_size, uncomp_size, lane);
-        R.hash = uni64(R.hash);
-    } else {
-        R.hash = xxh3_64_wave(dst, uncomp_size, lane);
-    }
+    lx_finish(O, dst, uncomp_size, R, lane);
 #ifdef LX_STATS
 #ifndef LX_STATS_SCAN_ONLY
     if (lx_dbg && lane == 0) { for (int k = 0; k < 12; k++) lx_dbg[k] = O.tm[k]; lx_dbg[12] = __builtin_amdgcn_s_memtime() - t_begin; }

@@ -28,6 +28,7 @@
 #endif
 #include "zstd_wg.h"
 #include "zstd_fse4.h"
+#include "zstd_ring.h"
 
 using namespace zpk;
 
@@ -288,7 +289,21 @@ __global__ __launch_bounds__(64, LX_WAVES_PER_SIMD) void k_lz4_exec(const u8* __
 // (result written, zstate = 2); everything else is left to k_zstd, so the verdict of every entry that is not
 // byte-exact with its checksum is always the full decoder's.
 #define ZSTD_EXEC_GRID_MAX 4096
-__global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
+#ifndef ZSTD_EXEC_WAVES
+#ifdef ZSTD_EXEC_RING
+#define ZSTD_EXEC_WAVES 3
+#else
+#define ZSTD_EXEC_WAVES 4
+#endif
+#endif
+// ZSTD_EXEC_RING (build-time, experimental): the execute stage through the LDS output ring (zstd_ring.h) — bit-exact, but slower
+// than the direct executor as measured (profiles/r02): the larger LDS footprint costs more waves than the ring saves traffic
+#ifndef ZSTD_EXEC_RING
+#define ZSTD_EXEC_LDS_BYTES ZSTD_SHARED_EXEC_BYTES
+#else
+#define ZSTD_EXEC_LDS_BYTES ZSTD_RING_SHARED_BYTES
+#endif
+__global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                                u8* dst, zpk_decode_result* __restrict__ res,
                                                                const u32* __restrict__ list, u32* __restrict__ counters,
                                                                u8* __restrict__ lit_scratch, const u64* __restrict__ arena,
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
     const int lane = lane_id();
     const u32 nz = uni(counters[L_ZSTD]);
     if (nz == 0) return;
-    __shared__ __attribute__((aligned(16))) u8 sh_raw[ZSTD_SHARED_EXEC_BYTES];
+    __shared__ __attribute__((aligned(16))) u8 sh_raw[ZSTD_EXEC_LDS_BYTES];
     ZstdShared& sh = *(ZstdShared*)sh_raw;
     if (threadIdx.x == 0) { sh.defaults_built = 0; sh.huf_valid = 0; }
     __syncthreads();
@@ -321,18 +336,9 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
         u8* out = uni_ptr(dst + d.dst_offset);
         const u64* const pre = arena + (((u64)d.dst_offset + 7) >> 3);
         Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
-#ifdef ZPK_STATS
-        ZstdStats zs = {};
-        const u64 t_all = SEQ_T();
-        DecodeOut o = zstd_decode_wave<true>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, &zs, pre);
-        if (dbg && lane == 0) {
-            u64* g = dbg + (u64)e * 8;
-            g[0] = zs.t_lit; g[1] = zs.t_tab; g[2] = zs.t_fse; g[3] = zs.t_exec; g[4] = zs.nseq; g[5] = zs.nblk; g[6] = SEQ_T() - t_all; g[7] = 1;
-        }
-#else
+#ifndef ZSTD_EXEC_RING
         (void)dbg;
         DecodeOut o = zstd_decode_wave<true>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, nullptr, pre);
-#endif
         bool ok = o.rc == D_OK;
         u64 h = 0;
         lane0_guard();
@@ -341,6 +347,15 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 4) void k_zstd_exec(const u8* __re
             h = xxh3_64_wave(out, d.uncomp_size, lane);                            // lib/zpack_read.c:466
             ok = h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH);
         }
+#else
+        (void)dbg;
+        // through the LDS output ring (zstd_ring.h): the hash comes out of the flushes
+        struct { int rc; u64 produced; } o;
+        const LxResult xr = zstd_ring_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), uni64(d.uncomp_size), lit, pre, lane);
+        o.rc = xr.rc == LX_OK ? D_OK : -(0x100 + xr.rc); o.produced = xr.produced;
+        const u64 h = xr.hash;
+        bool ok = xr.rc == LX_OK && xr.produced == uni64(d.uncomp_size) && (h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH));
+#endif
         lane0_guard();
         if (lane == 0) {
             if (ok) {

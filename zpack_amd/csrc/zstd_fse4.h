@@ -25,46 +25,53 @@
 namespace zpk {
 
 #define ZF_ROWS 4
-#define ZF_RING 512u                               // two 256-byte chunks of the backward bitstream
+#define ZF_CHUNK 64u                               // the backward bitstream moves through the ring in 64-byte chunks
+#define ZF_RING (2u * ZF_CHUNK)
+#define ZF_SEQBUF 8u                               // packed sequences a row collects before it stores them (one 64-byte store)
 #define ZF_SEQ_OFF_BITS 29                         // packed sequence: offset | match length << 29 | literal length << 47
 #define ZF_SEQ_ML_BITS 18
 #define ZF_SEQ_LL_BITS 17
-#define ZF_GRID_MAX (256u * 8u)                    // 8 workgroups per CU (LDS: 20 KiB each)
+#ifndef ZF_WG_PER_CU
+#define ZF_WG_PER_CU 12u                           // LDS: 12 708 B per workgroup = ten 1280-byte allocation units; 12 x 10 of the CU's 128
+#endif
+#define ZF_GRID_MAX (256u * ZF_WG_PER_CU)
 #define ZF_HEAD 8                                  // counters[] word used as this kernel's dequeue head
 #define ZF_WATCHDOG_WORD 11                        // counters[11]: entries given up by the row watchdog, [12]: header-loop budget hits
 #define ZF_COUNT_WORD 1                            // counters[] word holding the length of the Zstandard work list (L_ZSTD)
 
-// A decode-table cell takes 3 bytes here, split over two arrays so that LDS — which is what bounds the number of
-// streams in flight — holds 3.75 KiB of tables per stream instead of 5:
-//   s[i] (u16) = next_base (9 bits) | nb_bits << 9 (4) | (add_bits & 7) << 13        v[i] (u8) = add_bits >> 3 | symbol << 2
-// and a lane reassembles cell = s | v << 16: next_base = cell & 511, nb_bits = cell >> 9 & 15, add_bits = cell >> 13 & 31
-// (contiguous across the two halves), symbol = cell >> 18.
-struct ZfTab { u16 s_ll[512], s_ml[512], s_of[256]; u8 v_ll[512], v_ml[512], v_of[256]; };
+// LDS is what bounds the number of streams in flight, and the stage's throughput is proportional to that number (measured, round 2:
+// 4 / 6 / 8 workgroups per CU -> 34.7 / 25.7 / 19.2 ms on 16 384 text entries).  So a decode-table cell is TWO bytes here:
+//   cell = next-state counter n (10 bits: a symbol of count c owns the counters c .. 2c-1 <= 1023) | symbol << 10
+// and what the RFC 8878 4.1.1 table holds besides is recomputed from it: nb_bits = accuracy_log - highbit(n),
+// next_base = (n << nb_bits) - table size; the number of extra value bits follows from the symbol (zf_value_bits).  A stream
+// then takes 2.5 KiB of tables + 64 B of sequences + a 136-byte bitstream ring + 248 B of counts = 3 008 B.
+struct ZfTab { u16 c_ll[512], c_ml[512], c_of[256]; };
+#define ZF_NC_LL 0                                 // normalized counts: LL 36 symbols, OF 32, ML 53
+#define ZF_NC_OF 36
+#define ZF_NC_ML 68
 struct alignas(8) ZfRow {
     ZfTab t;
-    u64 seqbuf[16];                                // 16 packed sequences: the row flushes them as one 128-byte store
-    u8  ring[ZF_RING + 8];                         // + mirror of the first 8 bytes (reads are 8 bytes wide at any byte offset)
-    i16 ncount[3][64];                             // normalized counts, then (in place) the per-symbol next-state counters
+    u64 seqbuf[ZF_SEQBUF];                         // the row flushes them as one 64-byte store
+    u8  ring[ZF_RING + 8];                         // + mirror of the first 8 bytes (the dword pair of a read may straddle the wrap)
+    i16 ncount[124];                               // normalized counts, then (in place) the per-symbol next-state counters
 };
 struct alignas(16) ZfShared {
     ZfRow row[ZF_ROWS];
-    u16 ds_ll[64], ds_ml[64], ds_of[32];           // predefined distributions, same split
-    u8  dv_ll[64], dv_ml[64], dv_of[32];
-    u32 base_ll[36], base_ml[53], base_of[32];     // value baselines of the LL / ML / OF codes
+    u16 d_ll[64], d_ml[64], d_of[32];              // predefined distributions
+    u32 base_ll[36], base_ml[53];                  // value baselines of the LL / ML codes (offset codes: 1 << code)
 };
-__device__ __forceinline__ u32 zf_cell(u32 next_base, u32 nb, u32 add, u32 sym) { return next_base | (nb << 9) | (add << 13) | (sym << 18); }
-__device__ __forceinline__ u32 zf_next(u32 c) { return c & 511u; }
-__device__ __forceinline__ u32 zf_sym(u32 c)  { return (c >> 18) & 63u; }
+static_assert(sizeof(ZfShared) <= 12800, "k_zstd_fse: 12 workgroups per CU need <= 10 LDS allocation units each");
+__device__ __forceinline__ int zf_nc_base(int kind) { return kind == T_LL ? ZF_NC_LL : (kind == T_OF ? ZF_NC_OF : ZF_NC_ML); }
 
 // Decode table from normalized counts, by ONE lane, in place: the spread symbols are parked in the table itself
 // and the next-state counters overwrite the counts.  Same construction as fse_build_lane (zstd_wg.h).
-__device__ __noinline__ bool fse_build_inplace(ZPK_LDS u16* ts, ZPK_LDS u8* tv, ZPK_LDS i16* nc, int nsym, int al, int kind)
+__device__ __noinline__ bool fse_build_inplace(ZPK_LDS u16* t, ZPK_LDS i16* nc, int nsym, int al)
 {
     const int size = 1 << al;
     int high = size;
     #pragma unroll 1
     for (int s = 0; s < nsym; s++)
-        if (nc[s] == -1) tv[--high] = (u8)s;
+        if (nc[s] == -1) t[--high] = (u16)s;
     const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     int pos = 0;
     #pragma unroll 1
@@ -73,7 +80,7 @@ __device__ __noinline__ bool fse_build_inplace(ZPK_LDS u16* ts, ZPK_LDS u8* tv, 
         if (f <= 0) continue;
         #pragma unroll 1
         for (int i = 0; i < f; i++) {
-            if (pos < high) tv[pos] = (u8)s;                    // positions >= high belong to the -1 symbols: skipped below
+            if (pos < high) t[pos] = (u16)s;                    // positions >= high belong to the -1 symbols: skipped below
             do { pos = (pos + step) & mask; } while (pos >= high);
         }
     }
@@ -82,13 +89,10 @@ __device__ __noinline__ bool fse_build_inplace(ZPK_LDS u16* ts, ZPK_LDS u8* tv, 
     for (int s = 0; s < nsym; s++) { const int f = nc[s]; nc[s] = (i16)(f == -1 ? 1 : (f > 0 ? f : 0)); }
     #pragma unroll 1
     for (int i = 0; i < size; i++) {
-        const u32 s = tv[i];
-        const u32 n = (u32)(u16)nc[s];
+        const u32 s = t[i];
+        const u32 n = (u32)(u16)nc[s];                          // count <= n < 2 x count <= 2 x size: 10 bits, and highbit(n) <= al
         nc[s] = (i16)(n + 1);
-        const u32 nb = (u32)al - (u32)highbit32(n);
-        const u32 add = kind == T_LL ? (u32)Z_LL_BITS[s < 36 ? s : 0] : (kind == T_ML ? (u32)Z_ML_BITS[s < 53 ? s : 0] : s);
-        const u32 c = zf_cell((n << nb) - (u32)size, nb, add, s);
-        ts[i] = (u16)c; tv[i] = (u8)(c >> 16);
+        t[i] = (u16)(n | (s << 10));
     }
     return true;
 }
@@ -106,11 +110,47 @@ __device__ __forceinline__ u128 zf_load16(const u8* bs, i32 size, i32 byte)
     }
     return v;
 }
-__device__ __forceinline__ void zf_ring_put(lds_p8 ring, i32 chunk, int sub, u128 v)
+// 4 bytes at stream offset `byte` of [bs, bs+size), zero outside
+__device__ __forceinline__ u32 zf_load4(const u8* bs, i32 size, i32 byte)
 {
-    const u32 slot = ((u32)chunk & 1u) * 256u;
-    lds_st128(ring + slot + 16u * (u32)sub, v);
-    if (slot == 0 && sub == 0) lds_st64(ring + ZF_RING, v.lo);
+    if (byte >= 0 && byte + 4 <= size) return ld32(bs + byte);
+    u32 v = 0;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) { const i32 b = byte + i; if (b >= 0 && b < size) v |= (u32)ld8(bs + b) << (8 * i); }
+    return v;
+}
+// chunk `chunk` of the stream (64 bytes: 4 per lane of the row) into its half of the ring
+__device__ __forceinline__ void zf_ring_put(lds_p8 ring, i32 chunk, int sub, u32 v)
+{
+    const u32 slot = ((u32)chunk & 1u) * ZF_CHUNK;
+    *(ZPK_LDS u32*)(ring + slot + 4u * (u32)sub) = v;
+    if (slot == 0 && sub < 2) *(ZPK_LDS u32*)(ring + ZF_RING + 4u * (u32)sub) = v;
+}
+// The table descriptions of a block (up to 256 bytes) are staged in REGISTERS, 16 bytes per lane of the row, and read with
+// ds_bpermute: dword W (row-uniform) is component W & 3 of lane W >> 2; zero beyond the 256 bytes
+__device__ __forceinline__ u32 zf_stage_word(const u128& d, u32 W, int lane)
+{
+    const u32 c = W & 3u;
+    const u32 mine = c == 0 ? (u32)d.lo : (c == 1 ? (u32)(d.lo >> 32) : (c == 2 ? (u32)d.hi : (u32)(d.hi >> 32)));
+    const u32 v = (u32)__shfl((int)mine, (lane & ~15) | (int)((W >> 2) & 15u), 64);
+    return W < 64u ? v : 0u;
+}
+__device__ __forceinline__ u32 zf_stage_bits(const u128& d, u32 bit, int lane)          // 32 bits from bit offset `bit`
+{
+    const u32 W = bit >> 5;
+    return __builtin_amdgcn_alignbit(zf_stage_word(d, W + 1, lane), zf_stage_word(d, W, lane), bit & 31u);
+}
+// extra value bits of an LL / ML / OF code (RFC 8878 3.1.1.3.2.1.1) without a table, per-lane constants by chain:
+//   code < t1: 0;  code < t2: max(1, (code - t1) >> 1);  else code - dl
+//   LL: t1 16, t2 25, dl 19 (16..24 -> 1,1,1,1,2,2,3,3,4; 25.. -> 6,7,..16)   ML: t1 32, t2 43, dl 36 (32..42 -> 1,1,1,1,2,2,3,3,4,4,5; 43.. -> 7..16)
+//   OF: t1 = t2 = dl = 0 (the code itself)
+struct ZfValueBits { u32 t1, t2, dl; };
+__device__ __forceinline__ u32 zf_value_bits(const ZfValueBits& c, u32 sym)
+{
+    const u32 h = (sym - c.t1) >> 1;
+    const u32 mid = h > 1u ? h : 1u;
+    const u32 v = sym < c.t2 ? mid : sym - c.dl;
+    return sym < c.t1 ? 0u : v;
 }
 // 32 stream bits starting at bit `bit`, out of the ring: TWO ALIGNED dword reads + one v_alignbit.  (The one 8-byte read at any byte
 // offset this replaces was the kernel's bottleneck: rocprofv3 round 2, SQ_LDS_UNALIGNED_STALL 2.9e9 + SQ_LDS_IDX_ACTIVE 3.9e9 of 6.9e9
@@ -118,9 +158,6 @@ __device__ __forceinline__ void zf_ring_put(lds_p8 ring, i32 chunk, int sub, u12
 __device__ __forceinline__ u32 zf_ring_bits(lds_cp8 ring, i32 bit)
 {
     const u32 byte = (u32)(bit >> 3) & (ZF_RING - 1u);
-#ifdef ZF_OLD_RING_READ
-    return (u32)(((const ZPK_LDS pk64*)(ring + byte))->v >> (bit & 7));
-#endif
     const ZPK_LDS u32* w = (const ZPK_LDS u32*)(ring + (byte & ~3u));          // the 8-byte mirror behind the ring covers w[1] at the wrap
     const u32 d0 = w[0], d1 = w[1];
     return __builtin_amdgcn_alignbit(d1, d0, ((byte & 3u) << 3) | ((u32)bit & 7u));
@@ -132,11 +169,12 @@ __device__ __forceinline__ u32 zf_bits(lds_cp8 ring, i32 bit, u32 n)
 }
 __device__ __forceinline__ u32 lds_ld32u(lds_cp8 p) { return ((const ZPK_LDS pk32*)p)->v; }
 
-// RFC 8878 4.1.1 out of a staged LDS buffer (row-uniform).  Returns bytes consumed or -1.
-__device__ __forceinline__ int zf_read_ncount(lds_cp8 buf, u32 size, u32 room, int max_sym, int max_al, ZPK_LDS i16* nc, int& nsym, int& al_out)
+// RFC 8878 4.1.1 out of the register stage, from its byte `o` on (row-uniform).  Returns bytes consumed or -1.
+__device__ __forceinline__ int zf_read_ncount(const u128& stage, u32 o, u32 size, u32 room, int max_sym, int max_al, ZPK_LDS i16* nc, int& nsym, int& al_out,
+                                              int lane)
 {
     u32 bit = 0;
-    #define ZF_RD(n) ({ const u32 w_ = lds_ld32u(buf + (bit >> 3)); const u32 v_ = (w_ >> (bit & 7)) & ((1u << (n)) - 1u); bit += (u32)(n); v_; })
+    #define ZF_RD(n) ({ const u32 w_ = zf_stage_bits(stage, 8u * o + bit, lane); const u32 v_ = w_ & ((1u << (n)) - 1u); bit += (u32)(n); v_; })
     const int al = 5 + (int)ZF_RD(4);
     if (al > max_al) return -1;
     int remaining = 1 << al;
@@ -178,7 +216,7 @@ __device__ __forceinline__ int zf_read_ncount(lds_cp8 buf, u32 size, u32 room, i
 enum { ZF_NEED_ENTRY = 0, ZF_NEED_FRAME = 1, ZF_NEED_BLOCK = 2, ZF_DECODING = 3, ZF_DONE = 4 };
 
 // state[e] = 1: entry e's sequences are in the arena (region of its output slot, 8 bytes per sequence); 0: not.
-__global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
+__global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                  const u32* __restrict__ list, u32* __restrict__ counters,
                                                  u64* __restrict__ arena, u32* __restrict__ state)
 {
@@ -190,15 +228,13 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
     const lds_p8 ring = (lds_p8)R->ring;
 
     // ---- predefined tables + symbol tables, once per workgroup ----
-    for (int i = lane; i < 36; i += WAVE) { sh.row[0].ncount[0][i] = Z_LL_DEF[i]; sh.base_ll[i] = Z_LL_BASE[i]; }
-    for (int i = lane; i < 29; i += WAVE) sh.row[1].ncount[0][i] = Z_OF_DEF[i];
-    for (int i = lane; i < 32; i += WAVE) sh.base_of[i] = 1u << i;
-    for (int i = lane; i < 53; i += WAVE) { sh.row[2].ncount[0][i] = Z_ML_DEF[i]; sh.base_ml[i] = Z_ML_BASE[i]; }
+    for (int i = lane; i < 36; i += WAVE) { sh.row[0].ncount[i] = Z_LL_DEF[i]; sh.base_ll[i] = Z_LL_BASE[i]; }
+    for (int i = lane; i < 29; i += WAVE) sh.row[1].ncount[i] = Z_OF_DEF[i];
+    for (int i = lane; i < 53; i += WAVE) { sh.row[2].ncount[i] = Z_ML_DEF[i]; sh.base_ml[i] = Z_ML_BASE[i]; }
     __syncthreads();
     if (lane < 3) {
-        ZPK_LDS u16* const ts = lane == T_LL ? (ZPK_LDS u16*)sh.ds_ll : (lane == T_OF ? (ZPK_LDS u16*)sh.ds_of : (ZPK_LDS u16*)sh.ds_ml);
-        ZPK_LDS u8* const tv = lane == T_LL ? (ZPK_LDS u8*)sh.dv_ll : (lane == T_OF ? (ZPK_LDS u8*)sh.dv_of : (ZPK_LDS u8*)sh.dv_ml);
-        fse_build_inplace(ts, tv, (ZPK_LDS i16*)sh.row[lane].ncount[0], lane == T_LL ? 36 : (lane == T_OF ? 29 : 53), lane == T_OF ? 5 : 6, lane);
+        ZPK_LDS u16* const t = lane == T_LL ? (ZPK_LDS u16*)sh.d_ll : (lane == T_OF ? (ZPK_LDS u16*)sh.d_of : (ZPK_LDS u16*)sh.d_ml);
+        fse_build_inplace(t, (ZPK_LDS i16*)sh.row[lane].ncount, lane == T_LL ? 36 : (lane == T_OF ? 29 : 53), lane == T_OF ? 5 : 6);
     }
     __syncthreads();
 
@@ -212,16 +248,20 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
     int al_ll = 0, al_of = 0, al_ml = 0;
     u32 remaining = 0;
     const u8* bs = nullptr; i32 bs_size = 0, pos = 0, loaded_lo = 0;
-    u128 pf; pf.lo = 0; pf.hi = 0;                       // per lane: its 16 bytes of the chunk below the ring
-    u32 cell = 0;                                        // per lane (chain lanes): s | v << 16
+    u32 pf = 0;                                          // per lane: its 4 bytes of the chunk below the ring
+    u32 cell = 0;                                        // per lane (chain lanes): next-state counter | symbol << 10
+    u32 my_al = 0;                                       // per lane: accuracy log of the lane's chain in the current block
     // roles inside a row (zstd_wg.h): lanes 0,1,2 cut the OF, ML, LL value bits, lanes 7,6,5 the state bits of the same chains
     const int role = sub < 3 ? sub : 7 - sub;            // 0 OF, 1 ML, 2 LL for chain lanes
     const bool chain = sub < 3 || (sub >= 5 && sub < 8);
-    const ZPK_LDS u16* const tabs = role == 0 ? (const ZPK_LDS u16*)R->t.s_of : (role == 1 ? (const ZPK_LDS u16*)R->t.s_ml : (const ZPK_LDS u16*)R->t.s_ll);
-    const ZPK_LDS u8* const tabv = role == 0 ? (const ZPK_LDS u8*)R->t.v_of : (role == 1 ? (const ZPK_LDS u8*)R->t.v_ml : (const ZPK_LDS u8*)R->t.v_ll);
-    const ZPK_LDS u32* const symt = role == 0 ? (const ZPK_LDS u32*)sh.base_of : (role == 2 ? (const ZPK_LDS u32*)sh.base_ll : (const ZPK_LDS u32*)sh.base_ml);
-    const u32 nsh = sub < 3 ? 13u : 9u;                  // where this lane's field width sits in a cell: add_bits (value lanes) / nb_bits (state lanes)
-    const u32 nmask = sub < 3 ? 31u : (chain ? 15u : 0u);
+    const ZPK_LDS u16* const tab = role == 0 ? (const ZPK_LDS u16*)R->t.c_of : (role == 1 ? (const ZPK_LDS u16*)R->t.c_ml : (const ZPK_LDS u16*)R->t.c_ll);
+    const ZPK_LDS u32* const symt = role == 2 ? (const ZPK_LDS u32*)sh.base_ll : (const ZPK_LDS u32*)sh.base_ml;     // (offset lanes: unused)
+    // value lanes (0..2 of a row) cut the extra bits of a code, state lanes (5..7) the bits of the state update.  The role of a lane is
+    // DATA (bit masks in VGPRs, opaque to the compiler), not control flow: per-role exec masks in the hot loop were SGPR spills + branches
+    u32 vmask = sub < 3 ? ~0u : 0u, smask = (chain && sub >= 3) ? ~0u : 0u, omask = role == 0 ? ~0u : 0u;
+    asm volatile("" : "+v"(vmask), "+v"(smask), "+v"(omask));
+    ZfValueBits vb;
+    vb.t1 = role == 0 ? 0u : (role == 1 ? 32u : 16u); vb.t2 = role == 0 ? 0u : (role == 1 ? 43u : 25u); vb.dl = role == 0 ? 0u : (role == 1 ? 36u : 19u);
     const u32 tmask = chain ? 511u : 0u;                 // idle lanes read cell 0
     u32 badv = 0;
     const u32 nz = counters[ZF_COUNT_WORD];
@@ -267,9 +307,9 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                 if (phase == ZF_NEED_FRAME) {
                     // frame header, as zstd_decode_wave
                     if (ip >= iend) {                                  // every frame of the entry walked: flush and publish
-                        const u32 rem = seq_n & 15u;
+                        const u32 rem = seq_n & (ZF_SEQBUF - 1u);
                         wave_mem_fence();
-                        if (!bad && rem && (u32)sub < rem) arena[a_base + (seq_n & ~15u) + (u32)sub] = R->seqbuf[sub];
+                        if (!bad && rem && (u32)sub < rem) arena[a_base + (seq_n & ~(ZF_SEQBUF - 1u)) + (u32)sub] = R->seqbuf[sub];
                         lane0_guard();
                         if (sub == 0) { state[e] = bad ? 0u : 1u; if (!bad) atomicAdd(&counters[ZF_WATCHDOG_WORD + 2], 1u); }
                         lane0_guard();
@@ -364,44 +404,34 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                         if (left < 1 || nseq > (u64)(seq_cap - seq_n)) ok = false;
                         u32 modes = 0;
                         if (ok) { modes = ld8(p); p += 1; left -= 1; }
-                        // stage up to 256 bytes of table descriptions in the (idle) ring
+                        // up to 256 bytes of table descriptions, staged in registers (zf_stage_bits)
                         const u32 avail = left < 256 ? (u32)left : 256u;
-                        if (ok) {
-                            wave_mem_fence();
-                            lds_st128(ring + 16u * (u32)sub, zf_load16(p, (i32)avail, 16 * sub));
-                            if (sub == 0) { u128 z; z.lo = 0; z.hi = 0; lds_st128(ring + 256, z); }
-                            wave_mem_fence();
-                        }
+                        u128 stage; stage.lo = 0; stage.hi = 0;
+                        if (ok) stage = zf_load16(p, (i32)avail, 16 * sub);
                         u32 o = 0;                                       // bytes of descriptions consumed
                         int pending = 0, ns[3] = {0, 0, 0};
                         #pragma unroll 1
                         for (int kind = 0; kind < 3 && ok; kind++) {      // T_LL, T_OF, T_ML: the order in the stream
                             const int mode = (int)((modes >> (6 - 2 * kind)) & 3);
-                            ZPK_LDS u16* const ts = kind == T_LL ? (ZPK_LDS u16*)R->t.s_ll : (kind == T_OF ? (ZPK_LDS u16*)R->t.s_of : (ZPK_LDS u16*)R->t.s_ml);
-                            ZPK_LDS u8* const tv = kind == T_LL ? (ZPK_LDS u8*)R->t.v_ll : (kind == T_OF ? (ZPK_LDS u8*)R->t.v_of : (ZPK_LDS u8*)R->t.v_ml);
+                            ZPK_LDS u16* const ts = kind == T_LL ? (ZPK_LDS u16*)R->t.c_ll : (kind == T_OF ? (ZPK_LDS u16*)R->t.c_of : (ZPK_LDS u16*)R->t.c_ml);
                             const int max_sym = kind == T_LL ? 35 : (kind == T_OF ? 31 : 52);
                             int al = 0;
                             if (mode == 0) {
-                                const ZPK_LDS u16* const dfs = kind == T_LL ? (const ZPK_LDS u16*)sh.ds_ll : (kind == T_OF ? (const ZPK_LDS u16*)sh.ds_of : (const ZPK_LDS u16*)sh.ds_ml);
-                                const ZPK_LDS u8* const dfv = kind == T_LL ? (const ZPK_LDS u8*)sh.dv_ll : (kind == T_OF ? (const ZPK_LDS u8*)sh.dv_of : (const ZPK_LDS u8*)sh.dv_ml);
+                                const ZPK_LDS u16* const dfs = kind == T_LL ? (const ZPK_LDS u16*)sh.d_ll : (kind == T_OF ? (const ZPK_LDS u16*)sh.d_of : (const ZPK_LDS u16*)sh.d_ml);
                                 const int n = kind == T_OF ? 32 : 64;
-                                for (int i = sub; i < n; i += 16) { ts[i] = dfs[i]; tv[i] = dfv[i]; }
+                                for (int i = sub; i < n; i += 16) ts[i] = dfs[i];
                                 al = kind == T_OF ? 5 : 6;
                             } else if (mode == 1) {
                                 if (o >= avail) ok = false;
                                 else {
-                                    const u32 s = lds_ld8((lds_cp8)ring + o);
+                                    const u32 s = zf_stage_bits(stage, 8u * o, lane) & 0xFFu;
                                     if ((int)s > max_sym) ok = false;
-                                    else {
-                                        const u32 add = kind == T_LL ? (u32)Z_LL_BITS[s] : (kind == T_ML ? (u32)Z_ML_BITS[s] : s);
-                                        const u32 c = zf_cell(0, 0, add, s);
-                                        ts[0] = (u16)c; tv[0] = (u8)(c >> 16); al = 0; o += 1;
-                                    }
+                                    else { ts[0] = (u16)(1u | (s << 10)); al = 0; o += 1; }      // one cell: counter 1 -> no state bits, next state 0
                                 }
                             } else if (mode == 2) {
                                 int nsym = 0;
-                                const int used2 = o < avail ? zf_read_ncount((lds_cp8)ring + o, avail - o, 272u - o, max_sym, kind == T_OF ? 8 : 9,
-                                                                             (ZPK_LDS i16*)R->ncount[kind], nsym, al) : -1;
+                                const int used2 = o < avail ? zf_read_ncount(stage, o, avail - o, 272u - o, max_sym, kind == T_OF ? 8 : 9,
+                                                                             (ZPK_LDS i16*)R->ncount + zf_nc_base(kind), nsym, al, lane) : -1;
                                 if (used2 < 0) ok = false;
                                 else { o += (u32)used2; ns[kind] = nsym; pending |= 1 << kind; }
                             } else {
@@ -415,10 +445,9 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                             bool bok = true;
                             const int kd = sub < 3 ? sub : 0;
                             if (sub < 3 && ((pending >> kd) & 1)) {
-                                ZPK_LDS u16* const ts = kd == T_LL ? (ZPK_LDS u16*)R->t.s_ll : (kd == T_OF ? (ZPK_LDS u16*)R->t.s_of : (ZPK_LDS u16*)R->t.s_ml);
-                                ZPK_LDS u8* const tv = kd == T_LL ? (ZPK_LDS u8*)R->t.v_ll : (kd == T_OF ? (ZPK_LDS u8*)R->t.v_of : (ZPK_LDS u8*)R->t.v_ml);
-                                bok = fse_build_inplace(ts, tv, (ZPK_LDS i16*)R->ncount[kd], kd == T_LL ? ns[T_LL] : (kd == T_OF ? ns[T_OF] : ns[T_ML]),
-                                                        kd == T_LL ? al_ll : (kd == T_OF ? al_of : al_ml), kd);
+                                ZPK_LDS u16* const ts = kd == T_LL ? (ZPK_LDS u16*)R->t.c_ll : (kd == T_OF ? (ZPK_LDS u16*)R->t.c_of : (ZPK_LDS u16*)R->t.c_ml);
+                                bok = fse_build_inplace(ts, (ZPK_LDS i16*)R->ncount + zf_nc_base(kd), kd == T_LL ? ns[T_LL] : (kd == T_OF ? ns[T_OF] : ns[T_ML]),
+                                                        kd == T_LL ? al_ll : (kd == T_OF ? al_of : al_ml));
                             }
                             wave_mem_fence();
                             if (((__ballot(!bok) >> (16 * row)) & 0xFFFFull) != 0) ok = false;
@@ -432,10 +461,10 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                             else {
                                 bs_size = (i32)bsz;
                                 pos = (i32)(bsz - 1) * 8 + highbit32(lastb);
-                                const i32 kt = (pos - 1) >> 11;
-                                const u128 c0 = zf_load16(bs, bs_size, 256 * kt + 16 * sub);
-                                const u128 c1 = zf_load16(bs, bs_size, 256 * (kt - 1) + 16 * sub);
-                                pf = zf_load16(bs, bs_size, 256 * (kt - 2) + 16 * sub);
+                                const i32 kt = (pos - 1) >> 9;                          // chunk of the stream's top bit
+                                const u32 c0 = zf_load4(bs, bs_size, (i32)ZF_CHUNK * kt + 4 * sub);
+                                const u32 c1 = zf_load4(bs, bs_size, (i32)ZF_CHUNK * (kt - 1) + 4 * sub);
+                                pf = zf_load4(bs, bs_size, (i32)ZF_CHUNK * (kt - 2) + 4 * sub);
                                 wave_mem_fence();
                                 zf_ring_put(ring, kt, sub, c0);
                                 zf_ring_put(ring, kt - 1, sub, c1);
@@ -446,7 +475,8 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                                 pos -= al_of; const u32 sof = zf_bits((lds_cp8)ring, pos, (u32)al_of);
                                 pos -= al_ml; const u32 sml = zf_bits((lds_cp8)ring, pos, (u32)al_ml);
                                 const u32 st0 = role == 0 ? sof : (role == 1 ? sml : (chain ? sll : 0u));
-                                cell = (u32)tabs[st0] | ((u32)tabv[st0] << 16);
+                                cell = tab[st0];
+                                my_al = role == 0 ? (u32)al_of : (role == 1 ? (u32)al_ml : (u32)al_ll);
                                 remaining = (u32)nseq;
                                 to_decode = true;
                             }
@@ -468,20 +498,24 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
         // lane needs to know about its role is a VGPR constant (no per-role exec masks: they were SGPR spills).
         if (phase == ZF_DECODING) {
             do {
-                const u32 n = (cell >> nsh) & nmask;                 // this lane's field width: value bits (lanes 0..2) / state bits (5..7)
+                const u32 cnt = cell & 1023u, sym = cell >> 10;        // next-state counter, symbol
+                const u32 nbs = my_al - (31u - (u32)__builtin_clz(cnt | 1u));      // state lanes: bits of the state update
+                const u32 n = (zf_value_bits(vb, sym) & vmask) | (nbs & smask);    // this lane's field width
                 u32 s = n;                                           // inclusive prefix over the row: fields are consumed in lane order
                 s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false);
                 s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false);
                 s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false);
                 const u32 total = (u32)__builtin_amdgcn_ds_swizzle((int)s, 0xF0);       // lane 7 of the row -> all 16 lanes
-                const u32 base = symt[zf_sym(cell)];
+                u32 tv = symt[sym];                                  // value baseline (LL / ML lanes); consumed after the state chain below
                 const i32 b = pos - (i32)s;
                 const u32 bits = zf_ring_bits((lds_cp8)ring, b) & ((1u << n) - 1u);
-                const u32 nst = zf_next(cell) + bits;                // lanes 5..7: next state (libzstd updates after the last sequence too)
+                const u32 nst = (cnt << nbs) - (1u << my_al) + bits;  // lanes 5..7: next state (libzstd updates after the last sequence too)
                 // lanes 0..3 take the mirrored lane's state (bank 0 of the row), lanes 4..7 keep their own
                 const u32 idx = (u32)__builtin_amdgcn_update_dpp((int)nst, (int)nst, 0x141, 0xf, 0x5, false);
-                const u32 ci = idx & tmask;
-                cell = (u32)tabs[ci] | ((u32)tabv[ci] << 16);
+                u32 ci = idx & tmask;
+                asm volatile("" : "+v"(tv), "+v"(ci));               // keeps the baseline's first use (and its wait) behind the ring read
+                cell = tab[ci];
+                const u32 base = (tv & ~omask) | ((1u << (sym & 31u)) & omask);
                 const u32 val = base + bits;                         // lanes 0..2: offset value, match length, literal length
                 const u32 llv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE6, 0xf, 0xf, false);     // quad_perm [2,1,2,3]
                 const u32 mlv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE5, 0xf, 0xf, false);     // quad_perm [1,1,2,3]
@@ -498,21 +532,21 @@ __global__ __launch_bounds__(64) void k_zstd_fse(const u8* __restrict__ src, con
                 }
                 // what does not fit the packing (or is corrupt) sends the entry to the fused decoder at the end of the block
                 badv |= (offset - 1u >= (1u << ZF_SEQ_OFF_BITS) - 1u ? 1u : 0u) | (mlv >> ZF_SEQ_ML_BITS) | (llv >> ZF_SEQ_LL_BITS);
-                if (sub == 0) R->seqbuf[seq_n & 15u] = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
+                if (sub == 0) R->seqbuf[seq_n & (ZF_SEQBUF - 1u)] = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
                 pos -= (i32)total;
                 seq_n += 1;
                 remaining -= 1;
-                if ((seq_n & 15u) == 0) {                            // 16 sequences = one 128-byte store
+                if ((seq_n & (ZF_SEQBUF - 1u)) == 0) {               // 8 sequences = one 64-byte store
                     wave_mem_fence();
-                    arena[a_base + (seq_n - 16u) + (u32)sub] = R->seqbuf[sub];
+                    arena[a_base + (seq_n - ZF_SEQBUF) + ((u32)sub & (ZF_SEQBUF - 1u))] = R->seqbuf[(u32)sub & (ZF_SEQBUF - 1u)];    // (lanes 8..15: the same again)
                     wave_mem_fence();
                 }
-                if (((pos - 160) >> 11) < loaded_lo) {             // the next reads reach below the ring: bring in the prefetched chunk
+                if (((pos - 160) >> 9) < loaded_lo) {              // the next reads reach below the ring: bring in the prefetched chunk
                     wave_mem_fence();
                     zf_ring_put(ring, loaded_lo - 1, sub, pf);
                     wave_mem_fence();
                     loaded_lo -= 1;
-                    pf = zf_load16(bs, bs_size, 256 * (loaded_lo - 1) + 16 * sub);
+                    pf = zf_load4(bs, bs_size, (i32)ZF_CHUNK * (loaded_lo - 1) + 4 * sub);
                 }
             } while (__ballot(remaining == 0) == 0);
             if (remaining == 0) {                                    // this row's block is done

@@ -868,14 +868,12 @@ __device__ __noinline__ int zstd_sequences(ZPK_LDS ZstdShared* sh, ZSeqArgs* a, 
     return D_OK;
 }
 
-template <bool EXEC_ONLY>
-__device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src, u64 size, const u8* rd_hi,
-                                 u8* dst, u64 dst_cap, u8* frame_lo, u8* lit_buf, u64& produced, int lane)
+// The literals section of a compressed block (RFC 8878 3.1.1.3.1): raw literals are used where they lie, RLE literals are one byte,
+// Huffman-coded ones are decoded into `lit_buf` (the workgroup's scratch).  `used` = bytes of the block the section takes.
+struct ZLiterals { const u8* lit; u64 lit_size, used; bool rle; u32 rle_byte; };
+__device__ inline int zstd_literals(ZstdShared& sh, ZFrameState& fs, const u8* src, u64 size, const u8* rd_hi, u8* lit_buf, ZLiterals& L, int lane)
 {
     ByteWindow win;
-    if (size < 3) return D_MALFORMED;
-    u64 zt0 = SEQ_T(); (void)zt0;
-    // ---- literals section ----
     const u32 b0 = uld8(src);
     const u32 type = b0 & 3, fmt = (b0 >> 2) & 3;
     const u8* lit = lit_buf; u64 lit_size = 0, used = 0;
@@ -912,6 +910,22 @@ __device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src,
         wave_mem_fence();
         lit_size = regen; used = hl + csize;
     }
+    L.lit = lit; L.lit_size = lit_size; L.used = used; L.rle = lit_rle; L.rle_byte = lit_rle_byte;
+    return D_OK;
+}
+
+template <bool EXEC_ONLY>
+__device__ inline int zstd_block(ZstdShared& sh, ZFrameState& fs, const u8* src, u64 size, const u8* rd_hi,
+                                 u8* dst, u64 dst_cap, u8* frame_lo, u8* lit_buf, u64& produced, int lane)
+{
+    ByteWindow win;
+    if (size < 3) return D_MALFORMED;
+    u64 zt0 = SEQ_T(); (void)zt0;
+    // ---- literals section ----
+    ZLiterals zl;
+    { const int lrc = zstd_literals(sh, fs, src, size, rd_hi, lit_buf, zl, lane); if (lrc != D_OK) return lrc; }
+    const u8* const lit = zl.lit; const u64 lit_size = zl.lit_size, used = zl.used;
+    const bool lit_rle = zl.rle; const u32 lit_rle_byte = zl.rle_byte;
     ZST({ u64 t = SEQ_T(); fs.zs->t_lit += t - zt0; zt0 = t; fs.zs->nblk++; });
     // ---- sequences header ----
     const u8* p = src + used;
