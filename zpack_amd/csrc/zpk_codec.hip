@@ -312,9 +312,14 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(
     const int lane = lane_id();
     const u32 nz = uni(counters[L_ZSTD]);
     if (nz == 0) return;
-    __shared__ __attribute__((aligned(16))) u8 sh_raw[ZSTD_EXEC_LDS_BYTES];
+#ifndef ZSTD_EXEC_RING
+    __shared__ __attribute__((aligned(16))) u8 sh_raw[ZSTD_SHARED_EXEC_BYTES];
     ZstdShared& sh = *(ZstdShared*)sh_raw;
     if (threadIdx.x == 0) { sh.defaults_built = 0; sh.huf_valid = 0; }
+#else
+    __shared__ ZstdRingShared sh;
+    if (threadIdx.x == 0) sh.huf_valid = 0;
+#endif
     __syncthreads();
     u8* lit = lit_scratch + (u64)blockIdx.x * ZSTD_LIT_SCRATCH;
     for (;;) {
@@ -337,8 +342,15 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(
         const u64* const pre = arena + (((u64)d.dst_offset + 7) >> 3);
         Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
 #ifndef ZSTD_EXEC_RING
+#ifdef ZPK_STATS
+        ZstdStats zs = {};
+        const u64 t_all = SEQ_T();
+        DecodeOut o = zstd_decode_wave<true>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, &zs, pre);
+        const u64 t_dec = SEQ_T();
+#else
         (void)dbg;
         DecodeOut o = zstd_decode_wave<true>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane, nullptr, pre);
+#endif
         bool ok = o.rc == D_OK;
         u64 h = 0;
         lane0_guard();
@@ -347,6 +359,12 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(
             h = xxh3_64_wave(out, d.uncomp_size, lane);                            // lib/zpack_read.c:466
             ok = h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH);
         }
+#ifdef ZPK_STATS
+        if (dbg && lane == 0) {
+            u64* g = dbg + (u64)e * 16;
+            g[0] = zs.t_lit; g[1] = zs.t_tab; g[2] = zs.t_fse; g[3] = zs.t_exec; g[4] = zs.nseq; g[5] = zs.nblk; g[6] = t_dec - t_all; g[7] = SEQ_T() - t_dec;
+        }
+#endif
 #else
         (void)dbg;
         // through the LDS output ring (zstd_ring.h): the hash comes out of the flushes

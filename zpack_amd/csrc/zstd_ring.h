@@ -16,7 +16,21 @@
 
 namespace zpk {
 
-#define ZSTD_RING_SHARED_BYTES (__builtin_offsetof(ZstdShared, ll) + LX_RING + 32u)
+// LDS of the ring executor's workgroup: the Huffman decode table and just the construction scratch the literals section needs (one
+// FSE table for the weights — the three sequence tables of ZstdShared are k_zstd_fse's business), then the output ring.
+// 9 584 B: 16 workgroups per CU, like the direct executor.
+struct alignas(16) ZstdRingShared {
+    u8  huf[4096];
+    u32 huf_rank[16];
+    union {
+        struct { FseCell wt[64]; i16 ncount[1][64]; u8 spread[1][512]; u16 nextc[1][64]; };
+        struct { u16 sym_start[256]; u32 huf_cnt[16]; };
+    };
+    u8  weights[256];
+    u32 huf_max_bits, huf_valid, pad0_, pad1_;
+    u8  ring[LX_RING + 32];
+};
+#define ZSTD_RING_SHARED_BYTES sizeof(ZstdRingShared)
 
 // the sequences of one block, 64 at a time: packed (zstd_fse4.h: offset 29 bits | match length 18 | literal length 17)
 __device__ inline int zr_sequences(LxOut& O, const u64* pre, u64 nseq, const ZLiterals& zl, const u8* lit_hi, u32 hist_lo, u64 dst_cap,
@@ -70,7 +84,7 @@ __device__ inline int zr_sequences(LxOut& O, const u64* pre, u64 nseq, const ZLi
 }
 
 // one compressed block (zstd_block<true> with the ring as its output)
-__device__ inline int zr_block(ZstdShared& sh, ZFrameState& fs, LxOut& O, const u8* src, u64 size, const u8* rd_hi, u32 hist_lo, u64 dst_cap,
+__device__ inline int zr_block(ZstdRingShared& sh, ZFrameState& fs, LxOut& O, const u8* src, u64 size, const u8* rd_hi, u32 hist_lo, u64 dst_cap,
                                u8* lit_buf, int lane)
 {
     if (size < 3) return LX_E_FRAME;
@@ -102,14 +116,14 @@ __device__ inline int zr_block(ZstdShared& sh, ZFrameState& fs, LxOut& O, const 
 }
 
 // every frame of an entry; the hash of the output comes out with it
-__device__ inline LxResult zstd_ring_decode_wave(ZstdShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u64 uncomp_size,
+__device__ inline LxResult zstd_ring_decode_wave(ZstdRingShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u64 uncomp_size,
                                                  u8* lit_buf, const u64* pre, int lane)
 {
     LxResult R; R.rc = LX_E_FRAME; R.produced = 0; R.hash = 0;
     if (dst_cap >= (1ull << 31) || uncomp_size >= (1ull << 31)) return R;       // positions are 32-bit here
     const u8* ip = src; const u8* const iend = src + src_size;
     LxOut O;
-    lx_begin(O, to_lds_rw((u8*)sh.ll), dst, uncomp_size, lane);
+    lx_begin(O, to_lds_rw(sh.ring), dst, uncomp_size, lane);
 #ifdef LX_STATS
     for (int k = 0; k < 12; k++) O.tm[k] = 0;
     O.t_last = __builtin_amdgcn_s_memtime();

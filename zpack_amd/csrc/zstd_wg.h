@@ -269,7 +269,8 @@ __device__ __forceinline__ FseCell lds_cell(const FseCell* tab, u32 state) { ret
 // ---- Huffman ------------------------------------------------------------------------------------
 
 // weights[0..n) are in LDS (n includes the implied last weight).  Whole wave; returns false if malformed.
-__device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
+template <class SH>
+__device__ inline bool huf_build(SH& sh, int n, int lane)
 {
     // rank counts + weight sum by lane 0 (n <= 256); counters live in LDS (dynamically indexed private arrays
     // cost registers this kernel does not have)
@@ -331,7 +332,8 @@ __device__ inline bool huf_build(ZstdShared& sh, int n, int lane)
 }
 
 // RFC 8878 4.2.1 Huffman tree description.  Returns bytes consumed or -1.  Uniform.
-__device__ inline int huf_read_tree(ZstdShared& sh, ByteWindow& win, const u8* src, u64 size, int lane)
+template <class SH>
+__device__ inline int huf_read_tree(SH& sh, ByteWindow& win, const u8* src, u64 size, int lane)
 {
     if (size < 1) return -1;
     const u32 hb = uld8(src);
@@ -425,6 +427,24 @@ struct HufBits {
         cb = ((pos + 7) >> 3) - 16;
         c_lo = fetch(cb); c_hi = fetch(cb + 8); pre = fetch(cb - 8); pre2 = fetch(cb - 16);
     }
+    // the same with the top of the container just above `pos` (at most 127 bits above its bottom): what window() expects
+    __device__ __forceinline__ void seek_w(i32 pos)
+    {
+        cb = ((pos + 7) >> 3) - 15;
+        c_lo = fetch(cb); c_hi = fetch(cb + 8); pre = fetch(cb - 8); pre2 = fetch(cb - 16);
+    }
+    // the 64 stream bits [pos - 64, pos), top-aligned (hi bit 31 = stream bit pos - 1): four codes of <= 11 bits can be decoded out of
+    // it with 32-bit shifts and no further container arithmetic.  pos <= cb*8 + 127 (seek_w; positions only go down).
+    __device__ __forceinline__ void window(i32 pos, u32& whi, u32& wlo)
+    {
+        while (pos - 64 < cb * 8) { c_hi = c_lo; c_lo = pre; pre = pre2; cb -= 8; pre2 = fetch(cb - 16); }
+        const u32 rel = (u32)(pos - 64 - cb * 8);                 // 0..63
+        const u32 d0 = (u32)c_lo, d1 = (u32)(c_lo >> 32), d2 = (u32)c_hi, d3 = (u32)(c_hi >> 32);
+        const bool up = rel >= 32u;
+        const u32 a0 = up ? d1 : d0, a1 = up ? d2 : d1, a2 = up ? d3 : d2;
+        wlo = __builtin_amdgcn_alignbit(a1, a0, rel & 31u);
+        whi = __builtin_amdgcn_alignbit(a2, a1, rel & 31u);
+    }
     // bits [bp, bp+n), n <= 12; bp may be negative (zeros below 0)
     __device__ __forceinline__ u32 peek(i32 bp, int n)
     {
@@ -456,7 +476,7 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
     for (int k = 0; k < HUF_NCP; k++) { r.cp[k] = HUF_CP_NONE; r.cr[k] = 0; }
     u32 wacc = 0;
     i32 pos = entry;
-    b.seek(pos);
+    b.seek_w(pos);
     bool merged = false, by_cp = false;
     // the highest checkpoint of the previous pass at or below the current position (positions only go down)
     i32 nxt = HUF_CP_NONE;
@@ -464,8 +484,69 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
         #pragma unroll
         for (int k = 0; k < HUF_NCP; k++) if (old.cp[k] <= pos && old.cp[k] > nxt) nxt = old.cp[k];
     }
+    if (MODE == 2 && WIDE) {
+        // ---- store pass, codes of <= 11 bits: the piece's symbol count is known (old.n), four symbols per window, one dword store ----
+        const ZPK_LDS u16* const tab = (const ZPK_LDS u16*)huf;
+        const u32 n = old.n, sh = 32u - (u32)mb;
+        u32 k = 0;
+        for (; k + 4u <= n; k += 4u) {
+            u32 whi, wlo, acc = 0, used = 0;
+            b.window(pos, whi, wlo);
+            #pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const u32 ent = tab[whi >> sh];
+                const u32 nb = ent >> 8;
+                acc |= (ent & 0xFFu) << (8 * t);
+                whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb);
+                wlo <<= nb;
+                used += nb;
+            }
+            st32(out + k, acc);
+            pos -= (i32)used;
+        }
+        if (k < n) {
+            u32 whi, wlo;
+            b.window(pos, whi, wlo);
+            for (; k < n; k++) {
+                const u32 ent = tab[whi >> sh];
+                const u32 nb = ent >> 8;
+                st8(out + k, (u8)ent);
+                whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb);
+                wlo <<= nb;
+                pos -= (i32)nb;
+            }
+        }
+        r.n = n; r.exit = pos;
+        return r;
+    }
     while (pos > lo) {
         const u32 rel = (u32)(top - pos);
+        if (MODE == 0 && WIDE && rel >= 128u && (r.n & 3u) == 0u) {
+            // ---- counting pass, past the mask window: rounds of four symbols while a whole round starts above `lo` ----
+            const ZPK_LDS u16* const tab = (const ZPK_LDS u16*)huf;
+            const u32 sh = 32u - (u32)mb;
+            const i32 need = 4 * mb;
+            u32 rounds = 0;
+            while (pos - need > lo) {
+                if (r.n >= 32u && (r.n & (r.n - 1u)) == 0u && r.n <= (32u << (HUF_NCP - 1))) {
+                    #pragma unroll
+                    for (int k = 0; k < HUF_NCP; k++) if (r.n == (32u << k)) { r.cp[k] = pos; r.cr[k] = r.n; }
+                }
+                if ((++rounds & 1023u) == 0u && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
+                u32 whi, wlo, used = 0;
+                b.window(pos, whi, wlo);
+                #pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const u32 nb = (u32)tab[whi >> sh] >> 8;
+                    whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb);
+                    wlo <<= nb;
+                    used += nb;
+                }
+                pos -= (i32)used;
+                r.n += 4u;
+            }
+            if (bad || pos <= lo) break;
+        }
         if (MODE != 2 && rel < 128) {
             const u64 bit = 1ull << (rel & 63);
             if (MODE == 1 && ((rel < 64 ? old.m0 : old.m1) & bit)) { merged = true; break; }
@@ -871,7 +952,8 @@ __device__ __noinline__ int zstd_sequences(ZPK_LDS ZstdShared* sh, ZSeqArgs* a, 
 // The literals section of a compressed block (RFC 8878 3.1.1.3.1): raw literals are used where they lie, RLE literals are one byte,
 // Huffman-coded ones are decoded into `lit_buf` (the workgroup's scratch).  `used` = bytes of the block the section takes.
 struct ZLiterals { const u8* lit; u64 lit_size, used; bool rle; u32 rle_byte; };
-__device__ inline int zstd_literals(ZstdShared& sh, ZFrameState& fs, const u8* src, u64 size, const u8* rd_hi, u8* lit_buf, ZLiterals& L, int lane)
+template <class SH>
+__device__ inline int zstd_literals(SH& sh, ZFrameState& fs, const u8* src, u64 size, const u8* rd_hi, u8* lit_buf, ZLiterals& L, int lane)
 {
     ByteWindow win;
     const u32 b0 = uld8(src);
