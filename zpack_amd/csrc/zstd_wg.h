@@ -519,34 +519,88 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
         r.n = n; r.exit = pos;
         return r;
     }
-    while (pos > lo) {
-        const u32 rel = (u32)(top - pos);
-        if (MODE == 0 && WIDE && rel >= 128u && (r.n & 3u) == 0u) {
-            // ---- counting pass, past the mask window: rounds of four symbols while a whole round starts above `lo` ----
-            const ZPK_LDS u16* const tab = (const ZPK_LDS u16*)huf;
-            const u32 sh = 32u - (u32)mb;
-            const i32 need = 4 * mb;
-            u32 rounds = 0;
-            while (pos - need > lo) {
-                if (r.n >= 32u && (r.n & (r.n - 1u)) == 0u && r.n <= (32u << (HUF_NCP - 1))) {
-                    #pragma unroll
-                    for (int k = 0; k < HUF_NCP; k++) if (r.n == (32u << k)) { r.cp[k] = pos; r.cr[k] = r.n; }
-                }
-                if ((++rounds & 1023u) == 0u && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
-                u32 whi, wlo, used = 0;
-                b.window(pos, whi, wlo);
+    if constexpr (WIDE && MODE != 2) {
+        // ---- counting walks, codes of <= 11 bits: ROUNDS of four symbols out of one 64-bit window.  The positions a round visits are a
+        // small bit mask L (bit u = the position `u` bits below the round's start); the 128-bit visited mask, the merge test against
+        // the previous walk's mask and the checkpoint test are then a handful of operations per ROUND, not per symbol ----
+        const ZPK_LDS u16* const tab = (const ZPK_LDS u16*)huf;
+        const u32 sh = 32u - (u32)mb;
+        const i32 need = 4 * mb;
+        u32 rounds = 0;
+        while (pos > lo) {
+            if (r.n >= 32u && (r.n & (r.n - 1u)) == 0u && r.n <= (32u << (HUF_NCP - 1))) {
+                #pragma unroll
+                for (int k = 0; k < HUF_NCP; k++) if (r.n == (32u << k)) { r.cp[k] = pos; r.cr[k] = r.n; }       // cr: index for now
+            }
+            if ((++rounds & 255u) == 0u && __builtin_amdgcn_s_memrealtime() > deadline) { bad = true; break; }
+            u32 whi, wlo, used = 0, live_n = 4u;
+            u32 u1, u2, u3;                                       // the round's 2nd..4th symbol start this many bits below its start
+            u64 Ltail = 0;
+            b.window(pos, whi, wlo);
+            const bool whole = pos - need > lo;                   // every symbol of the round starts above `lo`
+            if (whole) {
+                u32 nb = (u32)tab[whi >> sh] >> 8;
+                whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb); wlo <<= nb; u1 = nb;
+                nb = (u32)tab[whi >> sh] >> 8;
+                whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb); wlo <<= nb; u2 = u1 + nb;
+                nb = (u32)tab[whi >> sh] >> 8;
+                whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb); wlo <<= nb; u3 = u2 + nb;
+                nb = (u32)tab[whi >> sh] >> 8;
+                used = u3 + nb;
+            } else {                                              // the end of the piece: symbol by symbol
+                live_n = 0; u1 = u2 = u3 = 0;
                 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const u32 nb = (u32)tab[whi >> sh] >> 8;
-                    whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb);
+                    const bool live = pos - (i32)used > lo;
+                    const u32 nb = live ? (u32)tab[whi >> sh] >> 8 : 0u;
+                    Ltail |= (live ? 1ull : 0ull) << used;
+                    whi = nb ? __builtin_amdgcn_alignbit(whi, wlo, 32u - nb) : whi;
                     wlo <<= nb;
                     used += nb;
+                    live_n += live ? 1u : 0u;
                 }
-                pos -= (i32)used;
-                r.n += 4u;
             }
-            if (bad || pos <= lo) break;
+            // positions visited by this round: bit u = `u` bits below its start (u <= 33)
+            #define HUF_ROUND_MASK() (whole ? ((u64)(1u | (1u << u1) | (1u << u2)) | (1ull << u3)) : Ltail)
+            const u32 rel = (u32)(top - pos);
+            if (MODE == 1) {
+                const u64 L = HUF_ROUND_MASK();
+                u64 slice = 0;                                    // the previous walk's visited positions, as seen from this round's start
+                if (rel < 64u) slice = (old.m0 >> rel) | (rel ? old.m1 << (64u - rel) : 0ull);
+                else if (rel < 128u) slice = old.m1 >> (rel - 64u);
+                u64 hit = L & slice;
+                const u32 cpoff = (u32)(pos - nxt);               // nxt <= pos (or NONE: huge)
+                const bool cphit = nxt != HUF_CP_NONE && cpoff < 64u && ((L >> cpoff) & 1ull);
+                if (cphit) hit |= 1ull << cpoff;
+                if (hit) {
+                    const u32 off = (u32)__ffsll((long long)hit) - 1u;
+                    const u64 below = L & ((1ull << off) - 1ull);
+                    by_cp = cphit && off == cpoff && !((L & slice) >> off & 1ull);
+                    if (rel < 64u) { r.m0 |= below << rel; r.m1 |= rel ? below >> (64u - rel) : 0ull; }
+                    else if (rel < 128u) r.m1 |= below << (rel - 64u);
+                    r.n += (u32)__popcll(below);
+                    pos -= (i32)off;
+                    merged = true;
+                    break;
+                }
+            }
+            if (rel < 128u) {
+                const u64 L = HUF_ROUND_MASK();
+                if (rel < 64u) { r.m0 |= L << rel; r.m1 |= rel ? L >> (64u - rel) : 0ull; }
+                else r.m1 |= L << (rel - 64u);
+            }
+            r.n += live_n;
+            pos -= (i32)used;
+            if (MODE == 1 && pos < nxt) {                         // passed it: the next checkpoint further down
+                nxt = HUF_CP_NONE;
+                #pragma unroll
+                for (int k = 0; k < HUF_NCP; k++) if (old.cp[k] <= pos && old.cp[k] > nxt) nxt = old.cp[k];
+            }
+            #undef HUF_ROUND_MASK
         }
+    } else {
+    while (pos > lo) {
+        const u32 rel = (u32)(top - pos);
         if (MODE != 2 && rel < 128) {
             const u64 bit = 1ull << (rel & 63);
             if (MODE == 1 && ((rel < 64 ? old.m0 : old.m1) & bit)) { merged = true; break; }
@@ -579,6 +633,7 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
         }
         pos -= (i32)nb;
         r.n++;
+    }
     }
     if (MODE == 2) for (u32 k = r.n & ~3u; k < r.n; k++) { st8(out + k, (u8)wacc); wacc >>= 8; }
     r.exit = pos;
