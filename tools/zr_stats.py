@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer: per-phase cycles of the Zstandard execute stage (needs a -DZPK_DEVELOPER -DZPK_STATS build selected with
-ZPACK_AMD_CODEC_SO, and ZPK_DEBUG_TIMING=1).  tools/zx_stats.py [entries] [mix]"""
+"""Developer: per-phase cycles of the Zstandard RING executor (needs a -DZPK_DEVELOPER -DZSTD_EXEC_RING -DLX_STATS -DLX_STATS_SCAN_ONLY=0
+build selected with ZPACK_AMD_CODEC_SO, and ZPK_DEBUG_TIMING=1).  tools/zr_stats.py [entries] [mix]"""
 import os, sys
 import numpy as np
 os.environ["ZPK_DEBUG_TIMING"] = "1"
@@ -21,9 +21,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 a = np.zeros((n, 16), dtype=np.uint64)
 codec._chk(codec.L.zpk_codec_debug_read(codec.h, a.ctypes.data, a.nbytes), "debug_read")
-names = ["literals", "huf fix-up rounds", "fix-up iterations", "sequences", "huf tree (in literals)", "nblk", "decode_total", "hash"]
-m = a[:, :8].astype(np.float64).mean(0)
-tot = m[6] + m[7]
-print("mean memtime ticks per entry (mix %d, %d entries): total %.0f" % (mix, n, tot))
+names = ["seq load+scan", "literals section", "-", "positions", "deps", "lit copy", "match copy", "rounds", "flush+hash", "headers/other", "finish", "-", "TOTAL"]
+m = a[:, :13].astype(np.float64).mean(0)
+print("mean cycles per entry (mix %d, %d entries):" % (mix, n))
 for k, v in zip(names, m):
-    print("  %-13s %12.0f  %5.1f %%" % (k, v, 100 * v / tot))
+    print("  %-16s %10.0f  %5.1f %%" % (k, v, 100 * v / m[12]))

@@ -599,10 +599,17 @@ __device__ __forceinline__ int lx_exec_batch(LxOut& O, u32& cnt, u32 ll, u32 ml,
     const lds_p8 ring = O.ring;
     LXT(4);
     // ---- literals: stage -> ring ----
+    // (both first loads — the literal run's and the early match's — are issued before either is used: when they come from memory
+    // (Zstandard literals, far matches) that is one round trip instead of two)
+    u128 mv0; mv0.lo = 0; mv0.hi = 0;
+    const u128 lv0 = L.load16(0u);
+#ifndef LX_ABL_NOMATCH
+    if (early) mv0 = lx_load16(O, sabs);
+#endif
 #ifndef LX_ABL_NOLIT
     {
         // every lane: its first 16 literal bytes (or fewer); the few longer runs go on in 16-byte steps, the last one overlapped
-        lds_or_piece(ring, o - O.rb, L.load16(0u), ll < 16 ? ll : 16u);
+        lds_or_piece(ring, o - O.rb, lv0, ll < 16 ? ll : 16u);
         u64 bm = __ballot(ll > 16);
         for (u32 c = 16; bm; c += 16) {
             const bool on = c < ll;
@@ -616,9 +623,7 @@ __device__ __forceinline__ int lx_exec_batch(LxOut& O, u32& cnt, u32 ll, u32 ml,
     // ---- matches whose whole source is older than this batch ----
 #ifndef LX_ABL_NOMATCH
     {
-        u128 v; v.lo = 0; v.hi = 0;
-        if (early) v = lx_load16(O, sabs);
-        lds_or_piece(ring, ms - O.rb, v, !early ? 0u : (ml < 16 ? ml : 16u));
+        lds_or_piece(ring, ms - O.rb, mv0, !early ? 0u : (ml < 16 ? ml : 16u));
         u64 bm = __ballot(early && ml > 16);
         for (u32 c = 16; bm; c += 16) {
             const bool on = early && c < ml;

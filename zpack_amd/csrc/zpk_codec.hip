@@ -369,7 +369,8 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(
         (void)dbg;
         // through the LDS output ring (zstd_ring.h): the hash comes out of the flushes
         struct { int rc; u64 produced; } o;
-        const LxResult xr = zstd_ring_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), uni64(d.uncomp_size), lit, pre, lane);
+        const LxResult xr = zstd_ring_decode_wave(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), uni64(d.uncomp_size), lit, pre, lane,
+                                                   dbg ? dbg + (u64)e * 16 : nullptr);
         o.rc = xr.rc == LX_OK ? D_OK : -(0x100 + xr.rc); o.produced = xr.produced;
         const u64 h = xr.hash;
         bool ok = xr.rc == LX_OK && xr.produced == uni64(d.uncomp_size) && (h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH));

@@ -73,9 +73,11 @@ __device__ inline int zr_sequences(LxOut& O, const u64* pre, u64 nseq, const ZLi
         if ((u64)(u32)__builtin_amdgcn_readlane((int)xl, (int)cnt - 1) > zl.lit_size - lit_pos) return LX_E_FRAME;
         const u64 my_lit = lit_pos + (xl - llx);
         int rc;
+        LXT(0);
         if (zl.rle) { LxLitFill F; F.byte = zl.rle_byte; rc = lx_exec_batch(O, cnt, ll, ml, off, F, hist_lo, dst_cap, lane, stt); }
         else { LxLitGlobal G; G.p = zl.lit + my_lit; G.rd_hi = lit_hi; rc = lx_exec_batch(O, cnt, ll, ml, off, G, hist_lo, dst_cap, lane, stt); }
         if (rc != LX_OK) return rc;
+        LXT(8);
         lit_pos += (u32)__builtin_amdgcn_readlane((int)xl, (int)cnt - 1);       // (the batch may have been cut to what fits the ring)
         base += cnt;
     }
@@ -89,7 +91,9 @@ __device__ inline int zr_block(ZstdRingShared& sh, ZFrameState& fs, LxOut& O, co
 {
     if (size < 3) return LX_E_FRAME;
     ZLiterals zl;
+    LXT(9);
     if (zstd_literals(sh, fs, src, size, rd_hi, lit_buf, zl, lane) != D_OK) return LX_E_FRAME;
+    LXT(1);
     const u8* const lit_hi = zl.lit == lit_buf ? lit_buf + ZSTD_LIT_SCRATCH : rd_hi;
     const u8* p = src + zl.used;
     u64 left = size - zl.used;
@@ -117,8 +121,9 @@ __device__ inline int zr_block(ZstdRingShared& sh, ZFrameState& fs, LxOut& O, co
 
 // every frame of an entry; the hash of the output comes out with it
 __device__ inline LxResult zstd_ring_decode_wave(ZstdRingShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u64 uncomp_size,
-                                                 u8* lit_buf, const u64* pre, int lane)
+                                                 u8* lit_buf, const u64* pre, int lane, u64* lx_dbg = nullptr)
 {
+    (void)lx_dbg;
     LxResult R; R.rc = LX_E_FRAME; R.produced = 0; R.hash = 0;
     if (dst_cap >= (1ull << 31) || uncomp_size >= (1ull << 31)) return R;       // positions are 32-bit here
     const u8* ip = src; const u8* const iend = src + src_size;
@@ -127,6 +132,7 @@ __device__ inline LxResult zstd_ring_decode_wave(ZstdRingShared& sh, Watchdog& w
 #ifdef LX_STATS
     for (int k = 0; k < 12; k++) O.tm[k] = 0;
     O.t_last = __builtin_amdgcn_s_memtime();
+    const u64 t_begin = O.t_last;
 #endif
     u64 pre_idx = 0;
     __syncthreads();
@@ -202,7 +208,12 @@ __device__ inline LxResult zstd_ring_decode_wave(ZstdRingShared& sh, Watchdog& w
         pre_idx = fs.pre_idx;
         if (fn != 0 && (u64)(O.wp - frame_lo) != fcs) return R;
     }
+    LXT(9);
     lx_finish(O, dst, uncomp_size, R, lane);
+    LXT(10);
+#ifdef LX_STATS
+    if (lx_dbg && lane == 0) { for (int k = 0; k < 12; k++) lx_dbg[k] = O.tm[k]; lx_dbg[12] = __builtin_amdgcn_s_memtime() - t_begin; }
+#endif
     R.rc = LX_OK;
     return R;
 }

@@ -269,65 +269,69 @@ __device__ __forceinline__ FseCell lds_cell(const FseCell* tab, u32 state) { ret
 // ---- Huffman ------------------------------------------------------------------------------------
 
 // weights[0..n) are in LDS (n includes the implied last weight).  Whole wave; returns false if malformed.
+// Lane l holds symbols l, l + 64, l + 128, l + 192; the per-weight counts, every symbol's place among the symbols of its weight
+// (natural order: RFC 8878 4.2.1) and the table fill are all lane-parallel (a lane-0 loop over up to 256 symbols, three times, was
+// 30 % of the literals phase on text and a quarter of it on 256-symbol alphabets: tools/zx_stats.py, round 2).
 template <class SH>
 __device__ inline bool huf_build(SH& sh, int n, int lane)
 {
-    // rank counts + weight sum by lane 0 (n <= 256); counters live in LDS (dynamically indexed private arrays
-    // cost registers this kernel does not have)
-    __shared__ u32 ok_flag;
-    if (lane < 16) { sh.huf_cnt[lane] = 0; sh.huf_rank[lane] = 0xFFFFFFFFu; }
-    __syncthreads();
-    lane0_guard();
-    if (lane == 0) {
-        u32 sum = 0; bool ok = true;
-        #pragma unroll 1
-        for (int i = 0; i < n; i++) {
-            u32 w = sh.weights[i];
-            if (w > 12) { ok = false; break; }
-            sh.huf_cnt[w]++;
-            if (w) sum += 1u << (w - 1);
+    u32 w[4];
+    #pragma unroll
+    for (int p = 0; p < 4; p++) { const int i = lane + 64 * p; w[p] = i < n ? (u32)sh.weights[i] : 0u; }
+    if (__ballot(w[0] > 12 || w[1] > 12 || w[2] > 12 || w[3] > 12) != 0) return false;
+    u32 part = 0;
+    #pragma unroll
+    for (int p = 0; p < 4; p++) part += w[p] ? 1u << (w[p] - 1) : 0u;
+    const u32 sum = (u32)__builtin_amdgcn_readlane((int)wave_scan_add(part), 63);
+    if (sum == 0 || (sum & (sum - 1))) return false;
+    const int mb = highbit32(sum);
+    if (mb < 1 || mb > 12) return false;
+    // counts per weight, and for every symbol the number of symbols of the same weight before it
+    const u64 lt = (1ull << lane) - 1ull;
+    u32 before[4] = {0, 0, 0, 0};
+    u32 rank_w[4] = {0, 0, 0, 0};                      // first table index of the symbol's weight class
+    u32 pos = 0, cnt1 = 0;
+    #pragma unroll
+    for (int wv = 1; wv <= 12; wv++) {
+        u32 run = 0;
+        #pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const u64 m = __ballot(w[p] == (u32)wv);
+            if (w[p] == (u32)wv) { before[p] = run + (u32)__popcll(m & lt); rank_w[p] = pos; }
+            run += (u32)__popcll(m);
         }
-        int mb = 0;
-        if (ok) {
-            if (sum == 0 || (sum & (sum - 1))) ok = false;
-            else { mb = highbit32(sum); if (mb < 1 || mb > 12) ok = false; }
+        if (wv == 1) cnt1 = run;
+        if (lane == 0) sh.huf_rank[wv] = wv <= mb ? pos : 0xFFFFFFFFu;
+        pos += run << (wv - 1);
+    }
+    if (cnt1 < 2 || (cnt1 & 1)) return false;                          // libzstd HUF_readStats
+    if (lane == 0) { sh.huf_rank[0] = 0xFFFFFFFFu; sh.huf_rank[13] = sh.huf_rank[14] = sh.huf_rank[15] = 0xFFFFFFFFu; sh.huf_max_bits = (u32)mb; }
+    // fill: symbols of one weight take consecutive ranges in natural order.  max_bits <= 11 (what libzstd emits for literals): 2^11 u16
+    // entries, symbol | code length << 8, fit the same 4 KiB, and the decoder gets the length with the symbol; a 12-bit code keeps the
+    // byte table + the rank thresholds.  Ranges of < 64 entries are written by the symbol's own lane, longer ones by the whole wave.
+    const bool wide = mb <= 11;
+    #pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const u32 i = (u32)(lane + 64 * p);
+        const u32 len = w[p] ? 1u << (w[p] - 1) : 0u;
+        const u32 base = rank_w[p] + before[p] * len;
+        const u32 ent = i | (((u32)mb + 1u - w[p]) << 8);
+        if (len && len < 64u) {
+            if (wide) for (u32 k = 0; k < len; k++) ((ZPK_LDS u16*)sh.huf)[base + k] = (u16)ent;
+            else for (u32 k = 0; k < len; k++) sh.huf[base + k] = (u8)i;
         }
-        if (ok && (sh.huf_cnt[1] < 2 || (sh.huf_cnt[1] & 1))) ok = false;          // libzstd HUF_readStats
-        if (ok) {
-            u32 pos = 0;
-            #pragma unroll 1
-            for (int w = 1; w <= mb; w++) { sh.huf_rank[w] = pos; pos += sh.huf_cnt[w] << (w - 1); }
-            sh.huf_max_bits = (u32)mb;
+        u64 big = __ballot(len >= 64u);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const u32 blen = (u32)__builtin_amdgcn_readlane((int)len, src), bbase = (u32)__builtin_amdgcn_readlane((int)base, src);
+            const u32 bent = (u32)__builtin_amdgcn_readlane((int)ent, src);
+            if (wide) for (u32 k = (u32)lane; k < blen; k += WAVE) ((ZPK_LDS u16*)sh.huf)[bbase + k] = (u16)bent;
+            else for (u32 k = (u32)lane; k < blen; k += WAVE) sh.huf[bbase + k] = (u8)bent;
         }
-        ok_flag = ok ? 1u : 0u;
     }
     __syncthreads();
-    if (!ok_flag) return false;
-    // fill: symbols of one weight take consecutive ranges in natural order -> serial over symbols per
-    // weight for the range starts (lane 0, running starts in huf_cnt), then all lanes fill the ranges
-    if (lane < 16) sh.huf_cnt[lane] = sh.huf_rank[lane];
-    __syncthreads();
-    lane0_guard();
-    if (lane == 0) {
-        #pragma unroll 1
-        for (int i = 0; i < n; i++) {
-            u32 w = sh.weights[i];
-            if (w) { const u32 st = sh.huf_cnt[w]; sh.sym_start[i] = (u16)st; sh.huf_cnt[w] = st + (1u << (w - 1)); }
-        }
-    }
-    __syncthreads();
-    #pragma unroll 1
-    for (int i = 0; i < n; i++) {
-        u32 w = sh.weights[i];
-        if (!w) continue;
-        u32 len = 1u << (w - 1), base = sh.sym_start[i];
-        // max_bits <= 11 (what libzstd emits for literals): 2^11 u16 entries, symbol | code length << 8, fit the same 4 KiB, and
-        // the decoder gets the length with the symbol; a 12-bit code keeps the byte table + the rank thresholds
-        if (sh.huf_max_bits <= 11) { const u16 ent = (u16)(i | ((sh.huf_max_bits + 1 - w) << 8)); for (u32 k = lane; k < len; k += WAVE) ((u16*)sh.huf)[base + k] = ent; }
-        else for (u32 k = lane; k < len; k += WAVE) sh.huf[base + k] = (u8)i;
-    }
-    __syncthreads();
-    sh.huf_valid = 1;
+    if (lane == 0) sh.huf_valid = 1;
     return true;
 }
 
@@ -384,20 +388,20 @@ __device__ inline int huf_read_tree(SH& sh, ByteWindow& win, const u8* src, u64 
     }
     __syncthreads();
     // implied last weight
-    __shared__ int lastw;
-    lane0_guard();
-    if (lane == 0) {
-        u32 sum = 0; bool ok = true;
-        for (int i = 0; i < n; i++) { u32 w = sh.weights[i]; if (w > 12) ok = false; else if (w) sum += 1u << (w - 1); }
-        lastw = -1;
-        if (ok && sum != 0) {
-            int mb = highbit32(sum) + 1;
+    int lastw = -1;
+    {
+        u32 part = 0; bool ok = true;
+        for (int i = lane; i < n; i += WAVE) { const u32 w = sh.weights[i]; if (w > 12) ok = false; else if (w) part += 1u << (w - 1); }
+        const u32 sum = (u32)__builtin_amdgcn_readlane((int)wave_scan_add(part), 63);
+        if (__ballot(!ok) == 0 && sum != 0) {
+            const int mb = highbit32(sum) + 1;
             if (mb <= 12) {
-                u32 left = (1u << mb) - sum;
+                const u32 left = (1u << mb) - sum;
                 if (!(left & (left - 1))) lastw = highbit32(left) + 1;
             }
         }
-        if (lastw >= 0) sh.weights[n] = (u8)lastw;
+        lane0_guard();
+        if (lastw >= 0 && lane == 0) sh.weights[n] = (u8)lastw;
     }
     __syncthreads();
     if (lastw < 0) return -1;
@@ -412,6 +416,14 @@ struct HufBits {
     i32 cb;               // container covers stream bits [cb*8, cb*8 + 128)
     u64 c_lo, c_hi, pre, pre2;  // pre / pre2 = the 8 + 8 bytes below c_lo, loaded two steps ahead: with 8-bit codes a step is
                                 // only 8 symbols, less than a memory round trip under load
+#ifdef HUF_PRE4
+    u64 pre3, pre4;
+#define HUF_SHIFT_DOWN() do { c_hi = c_lo; c_lo = pre; pre = pre2; pre2 = pre3; pre3 = pre4; cb -= 8; pre4 = fetch(cb - 32); } while (0)
+#define HUF_SEEK_PRE() do { pre = fetch(cb - 8); pre2 = fetch(cb - 16); pre3 = fetch(cb - 24); pre4 = fetch(cb - 32); } while (0)
+#else
+#define HUF_SHIFT_DOWN() do { c_hi = c_lo; c_lo = pre; pre = pre2; cb -= 8; pre2 = fetch(cb - 16); } while (0)
+#define HUF_SEEK_PRE() do { pre = fetch(cb - 8); pre2 = fetch(cb - 16); } while (0)
+#endif
 
     __device__ __forceinline__ u64 fetch(i32 byte) const
     {
@@ -425,19 +437,19 @@ struct HufBits {
     __device__ __forceinline__ void seek(i32 pos)             // the next reads lie just below bit `pos`
     {
         cb = ((pos + 7) >> 3) - 16;
-        c_lo = fetch(cb); c_hi = fetch(cb + 8); pre = fetch(cb - 8); pre2 = fetch(cb - 16);
+        c_lo = fetch(cb); c_hi = fetch(cb + 8); HUF_SEEK_PRE();
     }
     // the same with the top of the container just above `pos` (at most 127 bits above its bottom): what window() expects
     __device__ __forceinline__ void seek_w(i32 pos)
     {
         cb = ((pos + 7) >> 3) - 15;
-        c_lo = fetch(cb); c_hi = fetch(cb + 8); pre = fetch(cb - 8); pre2 = fetch(cb - 16);
+        c_lo = fetch(cb); c_hi = fetch(cb + 8); HUF_SEEK_PRE();
     }
     // the 64 stream bits [pos - 64, pos), top-aligned (hi bit 31 = stream bit pos - 1): four codes of <= 11 bits can be decoded out of
     // it with 32-bit shifts and no further container arithmetic.  pos <= cb*8 + 127 (seek_w; positions only go down).
     __device__ __forceinline__ void window(i32 pos, u32& whi, u32& wlo)
     {
-        while (pos - 64 < cb * 8) { c_hi = c_lo; c_lo = pre; pre = pre2; cb -= 8; pre2 = fetch(cb - 16); }
+        while (pos - 64 < cb * 8) HUF_SHIFT_DOWN();
         const u32 rel = (u32)(pos - 64 - cb * 8);                 // 0..63
         const u32 d0 = (u32)c_lo, d1 = (u32)(c_lo >> 32), d2 = (u32)c_hi, d3 = (u32)(c_hi >> 32);
         const bool up = rel >= 32u;
@@ -448,7 +460,7 @@ struct HufBits {
     // bits [bp, bp+n), n <= 12; bp may be negative (zeros below 0)
     __device__ __forceinline__ u32 peek(i32 bp, int n)
     {
-        while (bp < cb * 8) { c_hi = c_lo; c_lo = pre; pre = pre2; cb -= 8; pre2 = fetch(cb - 16); }
+        while (bp < cb * 8) HUF_SHIFT_DOWN();
         const int rel = bp - cb * 8;
         const u64 v = rel >= 64 ? c_hi >> (rel - 64) : (c_lo >> rel) | ((c_hi << 1) << (63 - rel));
         return (u32)v & ((1u << n) - 1u);
@@ -1035,9 +1047,11 @@ __device__ inline int zstd_literals(SH& sh, ZFrameState& fs, const u8* src, u64 
         if (regen > ZSTD_BLOCK_MAX || hl + csize > size) return D_MALFORMED;
         const u8* p = src + hl; u64 left = csize;
         if (type == 2) {
+            const u64 zt_tree = SEQ_T(); (void)zt_tree;
             int t = huf_read_tree(sh, win, p, left, lane);
             if (t < 0) return D_MALFORMED;
             p += t; left -= (u64)t;
+            ZST(fs.zs->nseq += SEQ_T() - zt_tree);               // (stats builds of the execute-only kernel: nseq = cycles in the tree description)
         } else if (!sh.huf_valid) return D_MALFORMED;
         __syncthreads();
         HufArgs ha; ha.p = p; ha.size = left; ha.nstreams = streams; ha.lit = lit_buf; ha.regen = regen; ha.rd_hi = rd_hi; ha.deadline = fs.wd->deadline;
