@@ -285,23 +285,20 @@ __global__ __launch_bounds__(64, LX_WAVES_PER_SIMD) void k_lz4_exec(const u8* __
 
 // Stage 2 of the two-stage Zstandard path: entries whose sequences k_zstd_fse left in the arena (zstate == 1) are run
 // here — Huffman literals, execution, XXH3 — by a kernel that carries neither the FSE decoder's code nor its tables:
-// 9.4 KiB of LDS and <= 128 VGPRs, 16 workgroups per CU instead of 12.  Only a VERIFIED entry is finished here
+// 9.4 KiB of LDS and <= 128 VGPRs, 16 workgroups per CU.  Only a VERIFIED entry is finished here
 // (result written, zstate = 2); everything else is left to k_zstd, so the verdict of every entry that is not
 // byte-exact with its checksum is always the full decoder's.
 #define ZSTD_EXEC_GRID_MAX 4096
 #ifndef ZSTD_EXEC_WAVES
-#ifdef ZSTD_EXEC_RING
-#define ZSTD_EXEC_WAVES 3
-#else
 #define ZSTD_EXEC_WAVES 4
 #endif
-#endif
-// ZSTD_EXEC_RING (build-time, experimental): the execute stage through the LDS output ring (zstd_ring.h) — bit-exact, but slower
-// than the direct executor as measured (profiles/r02): the larger LDS footprint costs more waves than the ring saves traffic
-#ifndef ZSTD_EXEC_RING
-#define ZSTD_EXEC_LDS_BYTES ZSTD_SHARED_EXEC_BYTES
-#else
-#define ZSTD_EXEC_LDS_BYTES ZSTD_RING_SHARED_BYTES
+// The execute stage runs through the LDS output ring (zstd_ring.h): aligned LDS accesses, near matches served from LDS, whole 1 KiB
+// lines flushed with the XXH3 accumulators fed on the way out.  Against the direct executor (zstd_sequences_pre + seq_exec_batch,
+// every sequence written to and gathered from HBM with exact-tail accesses, hash by re-reading; -DZSTD_EXEC_DIRECT keeps it) it moves
+// 34 % fewer bytes in and 27 % fewer out of HBM at the same speed (profiles/r02: text, 8192 x 256 KiB: FETCH 13.8 -> 9.1 GB raw,
+// WRITE 4.5 -> 3.3 GB; C3 62.4 vs 61.3 ms, C4 equal).
+#ifndef ZSTD_EXEC_DIRECT
+#define ZSTD_EXEC_RING 1
 #endif
 __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                                u8* dst, zpk_decode_result* __restrict__ res,
