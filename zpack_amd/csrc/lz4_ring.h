@@ -356,6 +356,7 @@ struct LxOut {
     u8* dst;             // the entry's output slot in memory
     u32 wp, rb, fp;      // abs output positions: next byte, ring[0], flushed up to (rb, fp multiples of 1 KiB; rb <= fp <= wp)
     u32 hash_blocks;     // 1 KiB blocks the fused XXH3 takes as whole blocks
+    lds_cp8 sec;         // the XXH3 secret in LDS (192 bytes), or null: constant memory
     Xxh3Lite xs;
 };
 
@@ -416,7 +417,7 @@ __device__ __forceinline__ void lx_flush_blocks(LxOut& O, int lane)
         st128(O.dst + O.fp + 16u * (u32)lane, v);
 #endif
 #ifndef LX_ABL_NOHASH
-        if ((O.fp >> 10) < O.hash_blocks) O.xs.block(v, lane);
+        if ((O.fp >> 10) < O.hash_blocks) O.xs.block(v, lane, O.sec);
 #endif
         O.fp += 1024u;
     }
@@ -688,9 +689,10 @@ __device__ __forceinline__ int lx_exec_batch(LxOut& O, u32& cnt, u32 ll, u32 ml,
 struct LxResult { int rc; u64 produced; u64 hash; };
 
 // init / finish of an entry's ring
-__device__ __forceinline__ void lx_begin(LxOut& O, lds_p8 ring, u8* dst, u64 uncomp_size, int lane)
+__device__ __forceinline__ void lx_begin(LxOut& O, lds_p8 ring, u8* dst, u64 uncomp_size, int lane, lds_p8 sec = nullptr)
 {
-    O.ring = ring; O.dst = dst;
+    O.ring = ring; O.dst = dst; O.sec = (lds_cp8)sec;
+    if (sec && lane < 12) lds_st128(sec + 16 * lane, ld128(XXH3_SECRET + 16 * lane));
     for (u32 c = 16u * (u32)lane; c < LX_RING + 32u; c += 1024u) { u128 z; z.lo = 0; z.hi = 0; lds_st128(O.ring + c, z); }     // ring bytes >= wp are zero, always
     wave_mem_fence();
     O.wp = 0; O.rb = 0; O.fp = 0;

@@ -190,15 +190,22 @@ struct Xxh3Lite {
     {
         Xxh3Wave w; w.init(lane); a0 = w.a0; a1 = w.a1;
     }
-    __device__ __forceinline__ void block(u128 d, int lane)
+    // `sec` = a copy of the 192-byte secret in LDS, or null (constant memory).  The constant-memory reads are vector loads: their
+    // s_waitcnt vmcnt(0) also waits for the 1 KiB flush store issued just before — a full store round trip per flushed block.
+    __device__ __forceinline__ void block(u128 d, int lane, lds_cp8 sec = nullptr)
     {
         const int q = lane & 3, s = lane >> 2;
+        u64 k0, k1, s0, s1;
+        if (sec) {
+            k0 = ((const ZPK_LDS u64*)(sec + 8 * s + 16 * q))[0]; k1 = ((const ZPK_LDS u64*)(sec + 8 * s + 16 * q))[1];
+            s0 = ((const ZPK_LDS u64*)(sec + 128 + 16 * q))[0];   s1 = ((const ZPK_LDS u64*)(sec + 128 + 16 * q))[1];
+        } else { k0 = sec64(8 * s + 16 * q); k1 = sec64(8 * s + 16 * q + 8); s0 = sec64(128 + 16 * q); s1 = sec64(128 + 16 * q + 8); }
         u64 c0, c1;
-        Xxh3Wave::slot(d.lo, d.hi, sec64(8 * s + 16 * q), sec64(8 * s + 16 * q + 8), c0, c1);
+        Xxh3Wave::slot(d.lo, d.hi, k0, k1, c0, c1);
         Xxh3Wave::reduce16(c0, c1);
         a0 += c0; a1 += c1;
-        a0 = ((a0 ^ (a0 >> 47)) ^ sec64(128 + 16 * q)) * ZPK_P32_1;
-        a1 = ((a1 ^ (a1 >> 47)) ^ sec64(128 + 16 * q + 8)) * ZPK_P32_1;
+        a0 = ((a0 ^ (a0 >> 47)) ^ s0) * ZPK_P32_1;
+        a1 = ((a1 ^ (a1 >> 47)) ^ s1) * ZPK_P32_1;
     }
     __device__ __forceinline__ u64 finish(const u8* p, u32 nstripes, const u8* end, u64 total_len, int lane)
     {

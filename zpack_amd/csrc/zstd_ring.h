@@ -18,7 +18,7 @@ namespace zpk {
 
 // LDS of the ring executor's workgroup: the Huffman decode table and just the construction scratch the literals section needs (one
 // FSE table for the weights — the three sequence tables of ZstdShared are k_zstd_fse's business), then the output ring.
-// 9 584 B: 16 workgroups per CU, like the direct executor.
+// 9 776 B: 16 workgroups per CU, like the direct executor.
 struct alignas(16) ZstdRingShared {
     u8  huf[4096];
     u32 huf_rank[16];
@@ -29,6 +29,7 @@ struct alignas(16) ZstdRingShared {
     u8  weights[256];
     u32 huf_max_bits, huf_valid, pad0_, pad1_;
     u8  ring[LX_RING + 32];
+    u8  secret[192];                             // XXH3 secret for the flush (xxh3_device.h, Xxh3Lite::block)
 };
 #define ZSTD_RING_SHARED_BYTES sizeof(ZstdRingShared)
 
@@ -128,7 +129,7 @@ __device__ inline LxResult zstd_ring_decode_wave(ZstdRingShared& sh, Watchdog& w
     if (dst_cap >= (1ull << 31) || uncomp_size >= (1ull << 31)) return R;       // positions are 32-bit here
     const u8* ip = src; const u8* const iend = src + src_size;
     LxOut O;
-    lx_begin(O, to_lds_rw(sh.ring), dst, uncomp_size, lane);
+    lx_begin(O, to_lds_rw(sh.ring), dst, uncomp_size, lane, to_lds_rw(sh.secret));
 #ifdef LX_STATS
     for (int k = 0; k < 12; k++) O.tm[k] = 0;
     O.t_last = __builtin_amdgcn_s_memtime();
