@@ -27,12 +27,12 @@ namespace zpk {
 #define ZF_ROWS 4
 #define ZF_CHUNK 64u                               // the backward bitstream moves through the ring in 64-byte chunks
 #define ZF_RING (2u * ZF_CHUNK)
-#define ZF_SEQBUF 8u                               // packed sequences a row collects before it stores them (one 64-byte store)
+#define ZF_SEQBUF 8u                               // packed sequences a row collects (in registers, one per lane) before it stores them: one 64-byte store
 #define ZF_SEQ_OFF_BITS 29                         // packed sequence: offset | match length << 29 | literal length << 47
 #define ZF_SEQ_ML_BITS 18
 #define ZF_SEQ_LL_BITS 17
 #ifndef ZF_WG_PER_CU
-#define ZF_WG_PER_CU 12u                           // LDS: 12 708 B per workgroup = ten 1280-byte allocation units; 12 x 10 of the CU's 128
+#define ZF_WG_PER_CU 12u                           // LDS: 12 452 B per workgroup = ten 1280-byte allocation units; 12 x 10 of the CU's 128
 #endif
 #define ZF_GRID_MAX (256u * ZF_WG_PER_CU)
 #define ZF_HEAD 8                                  // counters[] word used as this kernel's dequeue head
@@ -44,14 +44,13 @@ namespace zpk {
 //   cell = next-state counter n (10 bits: a symbol of count c owns the counters c .. 2c-1 <= 1023) | symbol << 10
 // and what the RFC 8878 4.1.1 table holds besides is recomputed from it: nb_bits = accuracy_log - highbit(n),
 // next_base = (n << nb_bits) - table size; the number of extra value bits follows from the symbol (zf_value_bits).  A stream
-// then takes 2.5 KiB of tables + 64 B of sequences + a 136-byte bitstream ring + 248 B of counts = 3 008 B.
+// then takes 2.5 KiB of tables + a 136-byte bitstream ring + 248 B of counts = 2 944 B.
 struct ZfTab { u16 c_ll[512], c_ml[512], c_of[256]; };
 #define ZF_NC_LL 0                                 // normalized counts: LL 36 symbols, OF 32, ML 53
 #define ZF_NC_OF 36
 #define ZF_NC_ML 68
 struct alignas(8) ZfRow {
     ZfTab t;
-    u64 seqbuf[ZF_SEQBUF];                         // the row flushes them as one 64-byte store
     u8  ring[ZF_RING + 8];                         // + mirror of the first 8 bytes (the dword pair of a read may straddle the wrap)
     i16 ncount[124];                               // normalized counts, then (in place) the per-symbol next-state counters
 };
@@ -264,6 +263,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
     vb.t1 = role == 0 ? 0u : (role == 1 ? 32u : 16u); vb.t2 = role == 0 ? 0u : (role == 1 ? 43u : 25u); vb.dl = role == 0 ? 0u : (role == 1 ? 36u : 19u);
     const u32 tmask = chain ? 511u : 0u;                 // idle lanes read cell 0
     u32 badv = 0;
+    u32 acc_lo = 0, acc_hi = 0;                          // per lane: sequence (seq_n & ~7) + (sub & 7) of the row's current group of eight, packed
     const u32 nz = counters[ZF_COUNT_WORD];
     // A row must never hold the GPU: an entry gets the size-proportional budget of zpk_device.h (like the fused decoder), and the header
     // loop a fixed budget of steps per wave; either limit just hands the entry (or the rest of the list) to k_zstd.
@@ -308,8 +308,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                     // frame header, as zstd_decode_wave
                     if (ip >= iend) {                                  // every frame of the entry walked: flush and publish
                         const u32 rem = seq_n & (ZF_SEQBUF - 1u);
-                        wave_mem_fence();
-                        if (!bad && rem && (u32)sub < rem) arena[a_base + (seq_n & ~(ZF_SEQBUF - 1u)) + (u32)sub] = R->seqbuf[sub];
+                        if (!bad && rem && (u32)sub < rem) arena[a_base + (seq_n & ~(ZF_SEQBUF - 1u)) + (u32)sub] = ((u64)acc_hi << 32) | acc_lo;
                         lane0_guard();
                         if (sub == 0) { state[e] = bad ? 0u : 1u; if (!bad) atomicAdd(&counters[ZF_WATCHDOG_WORD + 2], 1u); }
                         lane0_guard();
@@ -531,15 +530,22 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                     if (shift) { rep2 = n2; rep1 = rep0; rep0 = offset; }
                 }
                 // what does not fit the packing (or is corrupt) sends the entry to the fused decoder at the end of the block
-                badv |= (offset - 1u >= (1u << ZF_SEQ_OFF_BITS) - 1u ? 1u : 0u) | (mlv >> ZF_SEQ_ML_BITS) | (llv >> ZF_SEQ_LL_BITS);
-                if (sub == 0) R->seqbuf[seq_n & (ZF_SEQBUF - 1u)] = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
+                // (an offset is >= 1 by construction and repeat offsets were checked when they were new; match and literal lengths cannot
+                // reach their 18 / 17 bits: codes <= 52 / 35 give at most 131 074 / 131 071)
+                badv |= val > (1u << ZF_SEQ_OFF_BITS) + 2u ? 1u : 0u;
+                {   // lane 0's packed sequence goes to lane (seq_n & 7) of the row — and its twin 8 lanes up — in REGISTERS: a row keeps its
+                    // group of eight without LDS and without an exec mask for lane 0
+                    const u64 packed = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
+                    const u32 p_lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)packed, 0x150, 0xf, 0xf, false);          // row_newbcast:0
+                    const u32 p_hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(packed >> 32), 0x150, 0xf, 0xf, false);
+                    const bool mine = ((u32)sub & (ZF_SEQBUF - 1u)) == (seq_n & (ZF_SEQBUF - 1u));
+                    acc_lo = mine ? p_lo : acc_lo; acc_hi = mine ? p_hi : acc_hi;
+                }
                 pos -= (i32)total;
                 seq_n += 1;
                 remaining -= 1;
                 if ((seq_n & (ZF_SEQBUF - 1u)) == 0) {               // 8 sequences = one 64-byte store
-                    wave_mem_fence();
-                    arena[a_base + (seq_n - ZF_SEQBUF) + ((u32)sub & (ZF_SEQBUF - 1u))] = R->seqbuf[(u32)sub & (ZF_SEQBUF - 1u)];    // (lanes 8..15: the same again)
-                    wave_mem_fence();
+                    arena[a_base + (seq_n - ZF_SEQBUF) + ((u32)sub & (ZF_SEQBUF - 1u))] = ((u64)acc_hi << 32) | acc_lo;    // (lanes 8..15: the same again)
                 }
                 if (((pos - 160) >> 9) < loaded_lo) {              // the next reads reach below the ring: bring in the prefetched chunk
                     wave_mem_fence();
