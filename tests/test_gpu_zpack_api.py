@@ -217,7 +217,7 @@ def test_batch_write_then_batch_read_roundtrip(Z, method, level):
 def test_encoder_stress_alphabets_and_boundaries(Z, method, level):
     """Inputs aimed at the device encoders' corner cases — literal-heavy data over alphabets of 2..129 symbols with
     geometric / Fibonacci-like frequencies (Huffman depth beyond 11 bits -> the length limiter, 1-bit codes, the
-    128-weight limit of the direct tree description -> Raw fallback), short periods, constant data, and sizes around the
+    128-weight limit of the direct tree description -> FSE-compressed weights), short periods, constant data, and sizes around the
     64 KiB block and the 2 KiB Huffman threshold.  Every archive must decode bit-exactly with the oracle and with stock
     libzstd / liblz4 (compiled reference)."""
     rng = np.random.default_rng(12345)
@@ -226,8 +226,8 @@ def test_encoder_stress_alphabets_and_boundaries(Z, method, level):
     def add(name, arr):
         want.append(("%s_%03d" % (name, len(want)), np.asarray(arr, dtype=np.uint8).tobytes()))
 
-    for nsym in (2, 3, 17, 64, 127, 128, 129, 200):
-        base = 0 if nsym <= 128 else 40
+    for nsym in (2, 3, 17, 64, 127, 128, 129, 200, 256):       # > 128 symbols: FSE-compressed Huffman weights (RFC 8878 4.2.1.1)
+        base = 0 if nsym <= 128 or nsym == 256 else 40
         for kind in ("geom", "fib", "flat"):
             if kind == "geom":
                 p = 0.5 ** np.arange(1, nsym + 1, dtype=np.float64); p[-1] += 1 - p.sum()
