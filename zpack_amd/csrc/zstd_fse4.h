@@ -43,7 +43,7 @@ namespace zpk {
 // 4 / 6 / 8 workgroups per CU -> 34.7 / 25.7 / 19.2 ms on 16 384 text entries).  So a decode-table cell is TWO bytes here:
 //   cell = next-state counter n (10 bits: a symbol of count c owns the counters c .. 2c-1 <= 1023) | symbol << 10
 // and what the RFC 8878 4.1.1 table holds besides is recomputed from it: nb_bits = accuracy_log - highbit(n),
-// next_base = (n << nb_bits) - table size; the number of extra value bits follows from the symbol (zf_value_bits).  A stream
+// next_base = (n << nb_bits) - table size; the number of extra value bits comes with the symbol's baseline (one LDS read).  A stream
 // then takes 2.5 KiB of tables + a 136-byte bitstream ring + 248 B of counts = 2 944 B.
 struct ZfTab { u16 c_ll[512], c_ml[512], c_of[256]; };
 #define ZF_NC_LL 0                                 // normalized counts: LL 36 symbols, OF 32, ML 53
@@ -57,7 +57,7 @@ struct alignas(8) ZfRow {
 struct alignas(16) ZfShared {
     ZfRow row[ZF_ROWS];
     u16 d_ll[64], d_ml[64], d_of[32];              // predefined distributions
-    u32 base_ll[36], base_ml[53];                  // value baselines of the LL / ML codes (offset codes: 1 << code)
+    u32 base_ll[36], base_ml[53];                  // LL / ML codes: value baseline | extra bits << 24 (offset codes: 1 << code, `code` bits)
 };
 static_assert(sizeof(ZfShared) <= 12800, "k_zstd_fse: 12 workgroups per CU need <= 10 LDS allocation units each");
 __device__ __forceinline__ int zf_nc_base(int kind) { return kind == T_LL ? ZF_NC_LL : (kind == T_OF ? ZF_NC_OF : ZF_NC_ML); }
@@ -139,18 +139,6 @@ __device__ __forceinline__ u32 zf_stage_bits(const u128& d, u32 bit, int lane)  
     const u32 W = bit >> 5;
     return __builtin_amdgcn_alignbit(zf_stage_word(d, W + 1, lane), zf_stage_word(d, W, lane), bit & 31u);
 }
-// extra value bits of an LL / ML / OF code (RFC 8878 3.1.1.3.2.1.1) without a table, per-lane constants by chain:
-//   code < t1: 0;  code < t2: max(1, (code - t1) >> 1);  else code - dl
-//   LL: t1 16, t2 25, dl 19 (16..24 -> 1,1,1,1,2,2,3,3,4; 25.. -> 6,7,..16)   ML: t1 32, t2 43, dl 36 (32..42 -> 1,1,1,1,2,2,3,3,4,4,5; 43.. -> 7..16)
-//   OF: t1 = t2 = dl = 0 (the code itself)
-struct ZfValueBits { u32 t1, t2, dl; };
-__device__ __forceinline__ u32 zf_value_bits(const ZfValueBits& c, u32 sym)
-{
-    const u32 h = (sym - c.t1) >> 1;
-    const u32 mid = h > 1u ? h : 1u;
-    const u32 v = sym < c.t2 ? mid : sym - c.dl;
-    return sym < c.t1 ? 0u : v;
-}
 // 32 stream bits starting at bit `bit`, out of the ring: TWO ALIGNED dword reads + one v_alignbit.  (The one 8-byte read at any byte
 // offset this replaces was the kernel's bottleneck: rocprofv3 round 2, SQ_LDS_UNALIGNED_STALL 2.9e9 + SQ_LDS_IDX_ACTIVE 3.9e9 of 6.9e9
 // CU-cycles — an LDS access that is not naturally aligned costs ~26 extra LDS cycles on gfx950.)
@@ -227,9 +215,9 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
     const lds_p8 ring = (lds_p8)R->ring;
 
     // ---- predefined tables + symbol tables, once per workgroup ----
-    for (int i = lane; i < 36; i += WAVE) { sh.row[0].ncount[i] = Z_LL_DEF[i]; sh.base_ll[i] = Z_LL_BASE[i]; }
+    for (int i = lane; i < 36; i += WAVE) { sh.row[0].ncount[i] = Z_LL_DEF[i]; sh.base_ll[i] = Z_LL_BASE[i] | ((u32)Z_LL_BITS[i] << 24); }
     for (int i = lane; i < 29; i += WAVE) sh.row[1].ncount[i] = Z_OF_DEF[i];
-    for (int i = lane; i < 53; i += WAVE) { sh.row[2].ncount[i] = Z_ML_DEF[i]; sh.base_ml[i] = Z_ML_BASE[i]; }
+    for (int i = lane; i < 53; i += WAVE) { sh.row[2].ncount[i] = Z_ML_DEF[i]; sh.base_ml[i] = Z_ML_BASE[i] | ((u32)Z_ML_BITS[i] << 24); }
     __syncthreads();
     if (lane < 3) {
         ZPK_LDS u16* const t = lane == T_LL ? (ZPK_LDS u16*)sh.d_ll : (lane == T_OF ? (ZPK_LDS u16*)sh.d_of : (ZPK_LDS u16*)sh.d_ml);
@@ -249,7 +237,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
     const u8* bs = nullptr; i32 bs_size = 0, pos = 0, loaded_lo = 0;
     u32 pf = 0;                                          // per lane: its 4 bytes of the chunk below the ring
     u32 cell = 0;                                        // per lane (chain lanes): next-state counter | symbol << 10
-    u32 my_al = 0;                                       // per lane: accuracy log of the lane's chain in the current block
+    u32 my_al = 0, al_m31 = 0;                           // per lane: accuracy log of the lane's chain in the current block (and that minus 31)
     // roles inside a row (zstd_wg.h): lanes 0,1,2 cut the OF, ML, LL value bits, lanes 7,6,5 the state bits of the same chains
     const int role = sub < 3 ? sub : 7 - sub;            // 0 OF, 1 ML, 2 LL for chain lanes
     const bool chain = sub < 3 || (sub >= 5 && sub < 8);
@@ -259,8 +247,6 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
     // DATA (bit masks in VGPRs, opaque to the compiler), not control flow: per-role exec masks in the hot loop were SGPR spills + branches
     u32 vmask = sub < 3 ? ~0u : 0u, smask = (chain && sub >= 3) ? ~0u : 0u, omask = role == 0 ? ~0u : 0u;
     asm volatile("" : "+v"(vmask), "+v"(smask), "+v"(omask));
-    ZfValueBits vb;
-    vb.t1 = role == 0 ? 0u : (role == 1 ? 32u : 16u); vb.t2 = role == 0 ? 0u : (role == 1 ? 43u : 25u); vb.dl = role == 0 ? 0u : (role == 1 ? 36u : 19u);
     const u32 tmask = chain ? 511u : 0u;                 // idle lanes read cell 0
     u32 badv = 0;
     u32 acc_lo = 0, acc_hi = 0;                          // per lane: sequence (seq_n & ~7) + (sub & 7) of the row's current group of eight, packed
@@ -476,6 +462,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                                 const u32 st0 = role == 0 ? sof : (role == 1 ? sml : (chain ? sll : 0u));
                                 cell = tab[st0];
                                 my_al = role == 0 ? (u32)al_of : (role == 1 ? (u32)al_ml : (u32)al_ll);
+                                al_m31 = my_al - 31u;
                                 remaining = (u32)nseq;
                                 to_decode = true;
                             }
@@ -498,26 +485,25 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
         if (phase == ZF_DECODING) {
             do {
                 const u32 cnt = cell & 1023u, sym = cell >> 10;        // next-state counter, symbol
-                const u32 nbs = my_al - (31u - (u32)__builtin_clz(cnt | 1u));      // state lanes: bits of the state update
-                const u32 n = (zf_value_bits(vb, sym) & vmask) | (nbs & smask);    // this lane's field width
+                const u32 nbs = al_m31 + (u32)__builtin_clz(cnt);     // state lanes: bits of the state update = al - highbit(counter); counter >= 1
+                const u32 tv = symt[sym];                             // LL / ML lanes: value baseline | extra bits << 24
+                const u32 nv = ((tv >> 24) & ~omask) | (sym & omask); // value lanes: extra bits of the code (an offset code IS its bit count)
+                const u32 n = (nv & vmask) | (nbs & smask);           // this lane's field width
                 u32 s = n;                                           // inclusive prefix over the row: fields are consumed in lane order
                 s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false);
                 s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false);
                 s += (u32)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false);
                 const u32 total = (u32)__builtin_amdgcn_ds_swizzle((int)s, 0xF0);       // lane 7 of the row -> all 16 lanes
-                u32 tv = symt[sym];                                  // value baseline (LL / ML lanes); consumed after the state chain below
                 const i32 b = pos - (i32)s;
                 const u32 bits = zf_ring_bits((lds_cp8)ring, b) & ((1u << n) - 1u);
                 const u32 nst = (cnt << nbs) - (1u << my_al) + bits;  // lanes 5..7: next state (libzstd updates after the last sequence too)
                 // lanes 0..3 take the mirrored lane's state (bank 0 of the row), lanes 4..7 keep their own
                 const u32 idx = (u32)__builtin_amdgcn_update_dpp((int)nst, (int)nst, 0x141, 0xf, 0x5, false);
-                u32 ci = idx & tmask;
-                asm volatile("" : "+v"(tv), "+v"(ci));               // keeps the baseline's first use (and its wait) behind the ring read
-                cell = tab[ci];
-                const u32 base = (tv & ~omask) | ((1u << (sym & 31u)) & omask);
+                cell = tab[idx & tmask];
+                const u32 base = (tv & 0xFFFFFFu & ~omask) | ((1u << (sym & 31u)) & omask);
                 const u32 val = base + bits;                         // lanes 0..2: offset value, match length, literal length
-                const u32 llv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE6, 0xf, 0xf, false);     // quad_perm [2,1,2,3]
-                const u32 mlv = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0xE5, 0xf, 0xf, false);     // quad_perm [1,1,2,3]
+                const u32 llv = (u32)__builtin_amdgcn_mov_dpp((int)val, 0xE6, 0xf, 0xf, true);            // quad_perm [2,1,2,3]
+                const u32 mlv = (u32)__builtin_amdgcn_mov_dpp((int)val, 0xE5, 0xf, 0xf, true);            // quad_perm [1,1,2,3]
                 u32 offset;
                 {   // repeat offsets (RFC 8878 3.1.1.5), meaningful in lane 0 of the row
                     const bool big = val > 3;
@@ -532,12 +518,12 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                 // what does not fit the packing (or is corrupt) sends the entry to the fused decoder at the end of the block
                 // (an offset is >= 1 by construction and repeat offsets were checked when they were new; match and literal lengths cannot
                 // reach their 18 / 17 bits: codes <= 52 / 35 give at most 131 074 / 131 071)
-                badv |= val > (1u << ZF_SEQ_OFF_BITS) + 2u ? 1u : 0u;
+                badv |= val >> ZF_SEQ_OFF_BITS;                      // (offset values of 2^29 .. 2^29 + 2 would still fit: they go to the fused decoder too)
                 {   // lane 0's packed sequence goes to lane (seq_n & 7) of the row — and its twin 8 lanes up — in REGISTERS: a row keeps its
                     // group of eight without LDS and without an exec mask for lane 0
                     const u64 packed = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
-                    const u32 p_lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)packed, 0x150, 0xf, 0xf, false);          // row_newbcast:0
-                    const u32 p_hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(packed >> 32), 0x150, 0xf, 0xf, false);
+                    const u32 p_lo = (u32)__builtin_amdgcn_mov_dpp((int)(u32)packed, 0x150, 0xf, 0xf, true);                 // row_newbcast:0
+                    const u32 p_hi = (u32)__builtin_amdgcn_mov_dpp((int)(u32)(packed >> 32), 0x150, 0xf, 0xf, true);
                     const bool mine = ((u32)sub & (ZF_SEQBUF - 1u)) == (seq_n & (ZF_SEQBUF - 1u));
                     acc_lo = mine ? p_lo : acc_lo; acc_hi = mine ? p_hi : acc_hi;
                 }
