@@ -233,8 +233,8 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
     u32 rep0 = 1, rep1 = 4, rep2 = 8;
     bool tables_valid = false, last_block = false, cksum = false, bad = false;
     int al_ll = 0, al_of = 0, al_ml = 0;
-    u32 remaining = 0;
-    const u8* bs = nullptr; i32 bs_size = 0, pos = 0, loaded_lo = 0;
+    u32 seq_end = 0;                                     // seq_n at the end of the row's current block
+    const u8* bs = nullptr; i32 bs_size = 0, pos = 0, loaded_lo = 0, refill_below = 0;
     u32 pf = 0;                                          // per lane: its 4 bytes of the chunk below the ring
     u32 cell = 0;                                        // per lane (chain lanes): next-state counter | symbol << 10
     u32 my_al = 0, al_m31 = 0;                           // per lane: accuracy log of the lane's chain in the current block (and that minus 31)
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
     asm volatile("" : "+v"(vmask), "+v"(smask), "+v"(omask));
     const u32 tmask = chain ? 511u : 0u;                 // idle lanes read cell 0
     u32 badv = 0;
-    u32 acc_lo = 0, acc_hi = 0;                          // per lane: sequence (seq_n & ~7) + (sub & 7) of the row's current group of eight, packed
+    u32 acc_lo = 0, acc_hi = 0;                          // per lane: lane j of a row holds packed sequence (seq_n - 1 - j) of the row's entry
     const u32 nz = counters[ZF_COUNT_WORD];
     // A row must never hold the GPU: an entry gets the size-proportional budget of zpk_device.h (like the fused decoder), and the header
     // loop a fixed budget of steps per wave; either limit just hands the entry (or the rest of the list) to k_zstd.
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                     // frame header, as zstd_decode_wave
                     if (ip >= iend) {                                  // every frame of the entry walked: flush and publish
                         const u32 rem = seq_n & (ZF_SEQBUF - 1u);
-                        if (!bad && rem && (u32)sub < rem) arena[a_base + (seq_n & ~(ZF_SEQBUF - 1u)) + (u32)sub] = ((u64)acc_hi << 32) | acc_lo;
+                        if (!bad && rem && (u32)sub < rem) arena[a_base + (seq_n - 1u) - (u32)sub] = ((u64)acc_hi << 32) | acc_lo;
                         lane0_guard();
                         if (sub == 0) { state[e] = bad ? 0u : 1u; if (!bad) atomicAdd(&counters[ZF_WATCHDOG_WORD + 2], 1u); }
                         lane0_guard();
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                                 zf_ring_put(ring, kt, sub, c0);
                                 zf_ring_put(ring, kt - 1, sub, c1);
                                 wave_mem_fence();
-                                loaded_lo = kt - 1;
+                                loaded_lo = kt - 1; refill_below = (kt - 1) * 512 + 160;    // reads reach at most 160 bits below `pos`
                                 // initial states: LL, OF, ML
                                 pos -= al_ll; const u32 sll = zf_bits((lds_cp8)ring, pos, (u32)al_ll);
                                 pos -= al_of; const u32 sof = zf_bits((lds_cp8)ring, pos, (u32)al_of);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                                 cell = tab[st0];
                                 my_al = role == 0 ? (u32)al_of : (role == 1 ? (u32)al_ml : (u32)al_ll);
                                 al_m31 = my_al - 31u;
-                                remaining = (u32)nseq;
+                                seq_end = seq_n + (u32)nseq;
                                 to_decode = true;
                             }
                         }
@@ -519,29 +519,27 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                 // (an offset is >= 1 by construction and repeat offsets were checked when they were new; match and literal lengths cannot
                 // reach their 18 / 17 bits: codes <= 52 / 35 give at most 131 074 / 131 071)
                 badv |= val >> ZF_SEQ_OFF_BITS;                      // (offset values of 2^29 .. 2^29 + 2 would still fit: they go to the fused decoder too)
-                {   // lane 0's packed sequence goes to lane (seq_n & 7) of the row — and its twin 8 lanes up — in REGISTERS: a row keeps its
-                    // group of eight without LDS and without an exec mask for lane 0
+                {   // The row keeps its last sequences in REGISTERS, as a shift register along its lanes: every step the packed values move
+                    // one lane up (DPP row_shr:1) and lane 0 — which has no lane below it and therefore keeps the `old` operand — takes
+                    // the new one.  After eight steps lane j holds sequence (seq_n - 1 - j): no LDS, no exec mask, two instructions.
                     const u64 packed = (u64)offset | ((u64)mlv << ZF_SEQ_OFF_BITS) | ((u64)llv << (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS));
-                    const u32 p_lo = (u32)__builtin_amdgcn_mov_dpp((int)(u32)packed, 0x150, 0xf, 0xf, true);                 // row_newbcast:0
-                    const u32 p_hi = (u32)__builtin_amdgcn_mov_dpp((int)(u32)(packed >> 32), 0x150, 0xf, 0xf, true);
-                    const bool mine = ((u32)sub & (ZF_SEQBUF - 1u)) == (seq_n & (ZF_SEQBUF - 1u));
-                    acc_lo = mine ? p_lo : acc_lo; acc_hi = mine ? p_hi : acc_hi;
+                    acc_lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)packed, (int)acc_lo, 0x111, 0xf, 0xf, false);
+                    acc_hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(packed >> 32), (int)acc_hi, 0x111, 0xf, 0xf, false);
                 }
                 pos -= (i32)total;
                 seq_n += 1;
-                remaining -= 1;
                 if ((seq_n & (ZF_SEQBUF - 1u)) == 0) {               // 8 sequences = one 64-byte store
-                    arena[a_base + (seq_n - ZF_SEQBUF) + ((u32)sub & (ZF_SEQBUF - 1u))] = ((u64)acc_hi << 32) | acc_lo;    // (lanes 8..15: the same again)
+                    if ((u32)sub < ZF_SEQBUF) arena[a_base + (seq_n - 1u) - (u32)sub] = ((u64)acc_hi << 32) | acc_lo;
                 }
-                if (((pos - 160) >> 9) < loaded_lo) {              // the next reads reach below the ring: bring in the prefetched chunk
+                if (pos < refill_below) {                          // the next reads reach below the ring: bring in the prefetched chunk
                     wave_mem_fence();
                     zf_ring_put(ring, loaded_lo - 1, sub, pf);
                     wave_mem_fence();
-                    loaded_lo -= 1;
+                    loaded_lo -= 1; refill_below -= 512;
                     pf = zf_load4(bs, bs_size, (i32)ZF_CHUNK * (loaded_lo - 1) + 4 * sub);
                 }
-            } while (__ballot(remaining == 0) == 0);
-            if (remaining == 0) {                                    // this row's block is done
+            } while (__ballot(seq_n == seq_end) == 0);
+            if (seq_n == seq_end) {                                  // this row's block is done
                 // lane 0 of the row saw every sequence; libzstd 1.4.9: the stream must not be under-consumed
                 const u64 bm = __ballot(sub == 0 && badv != 0);
                 if (((bm >> (16 * row)) & 1ull) != 0 || pos > 0) bad = true;
