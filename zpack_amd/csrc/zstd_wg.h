@@ -501,21 +501,22 @@ __device__ __forceinline__ HufRun huf_run(HufBits& b, const ZPK_LDS u8* huf, con
         const ZPK_LDS u16* const tab = (const ZPK_LDS u16*)huf;
         const u32 n = old.n, sh = 32u - (u32)mb;
         u32 k = 0;
-        for (; k + 4u <= n; k += 4u) {
-            u32 whi, wlo, acc = 0, used = 0;
-            b.window(pos, whi, wlo);
-            #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const u32 ent = tab[whi >> sh];
-                const u32 nb = ent >> 8;
-                acc |= (ent & 0xFFu) << (8 * t);
-                whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb);
-                wlo <<= nb;
-                used += nb;
-            }
-            st32(out + k, acc);
-            pos -= (i32)used;
+        #define HUF_ROUND4(acc_) do { u32 whi, wlo, used = 0; acc_ = 0; b.window(pos, whi, wlo);                                  \
+            _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                                       \
+                const u32 ent = tab[whi >> sh]; const u32 nb = ent >> 8;                                                          \
+                acc_ |= (ent & 0xFFu) << (8 * t);                                                                                 \
+                whi = __builtin_amdgcn_alignbit(whi, wlo, 32u - nb); wlo <<= nb; used += nb;                                      \
+            } pos -= (i32)used; } while (0)
+        // sixteen symbols per store: every store of this pass is one more operation the next bitstream refill has to wait for (vmcnt
+        // counts loads and stores together)
+        for (; k + 16u <= n; k += 16u) {
+            u32 a0, a1, a2, a3;
+            HUF_ROUND4(a0); HUF_ROUND4(a1); HUF_ROUND4(a2); HUF_ROUND4(a3);
+            u128 v; v.lo = (u64)a0 | ((u64)a1 << 32); v.hi = (u64)a2 | ((u64)a3 << 32);
+            st128(out + k, v);
         }
+        for (; k + 4u <= n; k += 4u) { u32 acc; HUF_ROUND4(acc); st32(out + k, acc); }
+        #undef HUF_ROUND4
         if (k < n) {
             u32 whi, wlo;
             b.window(pos, whi, wlo);
