@@ -285,9 +285,9 @@ __global__ __launch_bounds__(64, LX_WAVES_PER_SIMD) void k_lz4_exec(const u8* __
 
 // Stage 2 of the two-stage Zstandard path: entries whose sequences k_zstd_fse left in the arena (zstate == 1) are run
 // here — Huffman literals, execution, XXH3 — by a kernel that carries neither the FSE decoder's code nor its tables:
-// 9.4 KiB of LDS and <= 128 VGPRs, 16 workgroups per CU.  Only a VERIFIED entry is finished here
-// (result written, zstate = 2); everything else is left to k_zstd, so the verdict of every entry that is not
-// byte-exact with its checksum is always the full decoder's.
+// 9.4 KiB of LDS and <= 128 VGPRs, 16 workgroups per CU.  Only a COMPLETE entry (every frame decoded, exactly uncomp_size bytes) is finished here
+// (result written, zstate = 2: status OK, or FILE_HASH_MISMATCH when its XXH3 differs — decoding it again could only find the same);
+// everything else is left to k_zstd, so every verdict other than those two is always the full decoder's.
 #define ZSTD_EXEC_GRID_MAX 4096
 #ifndef ZSTD_EXEC_WAVES
 #define ZSTD_EXEC_WAVES 4
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(
             h = xxh3_64_wave(out, d.uncomp_size, lane);                            // lib/zpack_read.c:466
             ok = h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH);
         }
+        const int ok_status = R_OK;
 #ifdef ZPK_STATS
         if (dbg && lane == 0) {
             u64* g = dbg + (u64)e * 16;
@@ -370,12 +371,16 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(
                                                    dbg ? dbg + (u64)e * 16 : nullptr);
         o.rc = xr.rc == LX_OK ? D_OK : -(0x100 + xr.rc); o.produced = xr.produced;
         const u64 h = xr.hash;
-        bool ok = xr.rc == LX_OK && xr.produced == uni64(d.uncomp_size) && (h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH));
+        // A complete, byte-exact decode is finished here whatever its checksum says: FILE_HASH_MISMATCH is the verdict of
+        // lib/zpack_read.c:466-468 for exactly this case, and decoding the entry a second time in k_zstd would only reach it again
+        // (the set of frames this path accepts equals the oracle's on 18 000 damaged frames: profiles/r02/r02_fuzz_ring_executor.log)
+        const bool ok = xr.rc == LX_OK && xr.produced == uni64(d.uncomp_size);
+        const int ok_status = (h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH)) ? R_OK : R_FILE_HASH_MISMATCH;
 #endif
         lane0_guard();
         if (lane == 0) {
             if (ok) {
-                zpk_decode_result r; r.status = R_OK; r.detail = 0; r.produced = o.produced; r.hash = h;
+                zpk_decode_result r; r.status = ok_status; r.detail = 0; r.produced = o.produced; r.hash = h;
                 res[e] = r;
                 zstate[e] = 2u;
                 atomicAdd(&counters[C_ZSTD_TWO_STAGE], 1u);
