@@ -266,10 +266,21 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         const u32 nst = C - cpos < LZ4W_CHUNK + LZ4W_SLACK ? C - cpos : LZ4W_CHUNK + LZ4W_SLACK;
         const u32 tok_end = C - cpos < LZ4W_CHUNK ? C : cpos + LZ4W_CHUNK;      // tokens of this chunk lie before tok_end
         wave_mem_fence();
-        for (u32 i = (u32)lane * 16; i < nst; i += WAVE * 16) {
-            const u8* g = ip + cpos + i;
-            if (i + 16 <= nst && g + 16 <= rd_hi) { u128 v = ld128(g); __builtin_memcpy(sh.stage + i, &v, 16); }
-            else for (u32 k = i; k < nst && k < i + 16; k++) sh.stage[k] = ld8(ip + cpos + k);
+        if (ip + cpos + ((nst + 15u) & ~15u) <= rd_hi) {
+            // the whole chunk by LDS-DMA (global_load_lds, 16 bytes per lane, no registers): up to four loads in flight, ONE wait — the
+            // register form below waits for every 1 KiB before it asks for the next
+            const u8* const g = ip + cpos + 16u * (u32)lane;
+            ZPK_LDS u8* const d0 = (ZPK_LDS u8*)sh.stage;
+            #pragma unroll
+            for (u32 i = 0; i < LZ4W_CHUNK + LZ4W_SLACK; i += WAVE * 16)
+                if (i + 16u * (u32)lane < nst) __builtin_amdgcn_global_load_lds((const ZPK_GLOBAL u32*)(g + i), (ZPK_LDS u32*)(d0 + i), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            for (u32 i = (u32)lane * 16; i < nst; i += WAVE * 16) {
+                const u8* g = ip + cpos + i;
+                if (i + 16 <= nst && g + 16 <= rd_hi) { u128 v = ld128(g); __builtin_memcpy(sh.stage + i, &v, 16); }
+                else for (u32 k = i; k < nst && k < i + 16; k++) sh.stage[k] = ld8(ip + cpos + k);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         u64 ts = SEQ_T(); (void)ts; SEQ_STAT(stt.t_stage += ts - tp0; stt.chunks++);
