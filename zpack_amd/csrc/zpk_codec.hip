@@ -465,6 +465,8 @@ struct zpk_codec {
     u8*  d_lit = nullptr;        u64 lit_cap = 0;
     // host-API staging
     u8*  d_src = nullptr;        u64 src_cap = 0;
+    u8*  h_pin[2] = {nullptr, nullptr};          // pinned staging of the host-pointer paths (ZPK_PIN_CHUNK bytes each), created on first use
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     u8*  d_dst = nullptr;        u64 dst_cap = 0;
     void* d_desc = nullptr;      u64 desc_cap = 0;
     void* d_res = nullptr;       u64 res_cap = 0;
@@ -566,6 +568,7 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     (void)hipFree(c->d_counters); (void)hipFree(c->d_lists); (void)hipFree(c->d_lit);
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
+    for (int k = 0; k < 2; k++) { if (c->h_pin[k]) (void)hipHostFree(c->h_pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
     (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_tok); (void)hipFree(c->d_lz4meta); (void)hipFree(c->d_units); (void)hipFree(c->d_pack); (void)hipFree(c->d_packed); (void)hipFree(c->d_packoff);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -722,6 +725,53 @@ int zpk_codec_decode_batch_device(zpk_codec* c, const uint8_t* src, uint64_t src
 // One sub-batch of the host path: entries [0, n) of hd/desc, whose slots (hd[i].dst_offset, already laid out) total
 // out_total bytes.  `image` is what gets staged: either the archive itself (span mode, src_offset = archive offsets,
 // staged range [lo, hi)) or a packed copy of just these payloads (gather mode: hd[i].src_offset already rewritten).
+#ifndef ZPK_PIN_CHUNK
+#define ZPK_PIN_CHUNK (32ull << 20)
+#endif
+static int pin_ready(zpk_codec* c)
+{
+    for (int k = 0; k < 2; k++) {
+        if (!c->h_pin[k] && hipHostMalloc((void**)&c->h_pin[k], ZPK_PIN_CHUNK, hipHostMallocDefault) != hipSuccess) { c->h_pin[k] = nullptr; snprintf(c->err, sizeof(c->err), "pinned staging: out of memory"); return ZPK_E_NOMEM; }
+        if (!c->pin_ev[k] && hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { c->pin_ev[k] = nullptr; return ZPK_E_LAUNCH; }
+    }
+    return ZPK_OK;
+}
+
+// Device range [d_base, d_base + total) back to the host in pieces of ZPK_PIN_CHUNK bytes through the two pinned buffers; piece j + 1 is
+// on the bus while piece j is scattered: entry i owns bytes [off(i), off(i) + len(i)) of the range (ascending in i) and goes to dst_ptrs[i].
+extern "C++" {
+template <class OffFn, class LenFn>
+static int d2h_scatter(zpk_codec* c, const u8* d_base, u64 total, u64 n, uint8_t* const* dst_ptrs, OffFn off, LenFn len, hipError_t& e)
+{
+    int rc = pin_ready(c);
+    if (rc) return rc;
+    if (total == 0) return ZPK_OK;
+    const u64 npieces = (total + ZPK_PIN_CHUNK - 1) / ZPK_PIN_CHUNK;
+    u64 ei = 0;                                                                       // first entry that may still reach into the current piece
+    e = hipMemcpyAsync(c->h_pin[0], d_base, total < ZPK_PIN_CHUNK ? total : ZPK_PIN_CHUNK, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(c->pin_ev[0], c->stream);
+    for (u64 j = 0; j < npieces && e == hipSuccess; j++) {
+        const int k = (int)(j & 1);
+        const u64 p0 = j * ZPK_PIN_CHUNK, p1 = p0 + ZPK_PIN_CHUNK < total ? p0 + ZPK_PIN_CHUNK : total;
+        if (j + 1 < npieces) {
+            const u64 q0 = p1, q1 = q0 + ZPK_PIN_CHUNK < total ? q0 + ZPK_PIN_CHUNK : total;
+            e = hipMemcpyAsync(c->h_pin[k ^ 1], d_base + q0, q1 - q0, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->pin_ev[k ^ 1], c->stream);
+            if (e != hipSuccess) break;
+        }
+        e = hipEventSynchronize(c->pin_ev[k]);
+        if (e != hipSuccess) break;
+        while (ei < n && off(ei) + len(ei) <= p0) ei++;
+        for (u64 i = ei; i < n && off(i) < p1; i++) {
+            const u64 o = off(i), l = len(i);
+            const u64 a = o > p0 ? o : p0, z = o + l < p1 ? o + l : p1;
+            if (z > a) memcpy(dst_ptrs[i] + (a - o), c->h_pin[k] + (a - p0), z - a);
+        }
+    }
+    return ZPK_OK;
+}
+}  // extern "C++"
+
 static int decode_host_chunk(zpk_codec* c, const u8* image, u64 image_size, u64 lo, u64 hi, zpk_decode_desc* hd,
                              const zpk_decode_desc* desc, u64 n, u64 out_total, uint8_t* const* dst_ptrs, zpk_decode_result* results)
 {
@@ -748,13 +798,12 @@ static int decode_host_chunk(zpk_codec* c, const u8* image, u64 image_size, u64 
         if (results[i].produced > desc[i].dst_capacity) results[i].produced = desc[i].dst_capacity;     // (cannot happen)
         produced_total += results[i].produced;
     }
-    if (n > 1 && produced_total && produced_total * 2 >= out_total) {                   // dense: one transfer, then a host scatter
-        u8* tmp = (u8*)malloc(out_total);
-        if (!tmp) return ZPK_E_NOMEM;
-        e = hipMemcpy(tmp, c->d_dst, out_total, hipMemcpyDeviceToHost);
-        if (e == hipSuccess)
-            for (u64 i = 0; i < n; i++) if (results[i].produced) memcpy(dst_ptrs[i], tmp + hd[i].dst_offset, results[i].produced);
-        free(tmp);
+    if (n > 1 && produced_total && produced_total * 2 >= out_total) {
+        // dense: the slots come back in pieces of ZPK_PIN_CHUNK bytes through two PINNED staging buffers — piece j + 1 is on the bus
+        // while piece j is scattered into the caller's (pageable) buffers.  (One hipMemcpy of everything into a fresh malloc, then
+        // the scatter, ran at 6.7 GB/s: page faults + the driver's own staging of pageable memory.)
+        rc = d2h_scatter(c, c->d_dst, out_total, n, dst_ptrs, [&](u64 i) { return (u64)hd[i].dst_offset; }, [&](u64 i) { return (u64)results[i].produced; }, e);
+        if (rc) return rc;
     } else {
         for (u64 i = 0; i < n && e == hipSuccess; i++)
             if (results[i].produced) e = hipMemcpy(dst_ptrs[i], c->d_dst + hd[i].dst_offset, results[i].produced, hipMemcpyDeviceToHost);
