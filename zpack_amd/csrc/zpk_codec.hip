@@ -17,6 +17,7 @@
 #include <new>
 #include <time.h>
 #include <pthread.h>
+#include <thread>
 
 
 #include "zpk_device.h"
@@ -728,6 +729,9 @@ int zpk_codec_decode_batch_device(zpk_codec* c, const uint8_t* src, uint64_t src
 #ifndef ZPK_PIN_CHUNK
 #define ZPK_PIN_CHUNK (32ull << 20)
 #endif
+#ifndef ZPK_SCATTER_THREADS
+#define ZPK_SCATTER_THREADS 4u
+#endif
 static int pin_ready(zpk_codec* c)
 {
     for (int k = 0; k < 2; k++) {
@@ -762,10 +766,24 @@ static int d2h_scatter(zpk_codec* c, const u8* d_base, u64 total, u64 n, uint8_t
         e = hipEventSynchronize(c->pin_ev[k]);
         if (e != hipSuccess) break;
         while (ei < n && off(ei) + len(ei) <= p0) ei++;
-        for (u64 i = ei; i < n && off(i) < p1; i++) {
-            const u64 o = off(i), l = len(i);
-            const u64 a = o > p0 ? o : p0, z = o + l < p1 ? o + l : p1;
-            if (z > a) memcpy(dst_ptrs[i] + (a - o), c->h_pin[k] + (a - p0), z - a);
+        u64 ej = ei;
+        while (ej < n && off(ej) < p1) ej++;
+        // the scatter of one piece, split over a few host threads by entry count (one thread copies at ~22 GB/s, the bus brings ~50)
+        auto part = [&](u64 lo_i, u64 hi_i) {
+            for (u64 i = lo_i; i < hi_i; i++) {
+                const u64 o = off(i), l = len(i);
+                const u64 a = o > p0 ? o : p0, z = o + l < p1 ? o + l : p1;
+                if (z > a) memcpy(dst_ptrs[i] + (a - o), c->h_pin[k] + (a - p0), z - a);
+            }
+        };
+        const u64 cnt = ej - ei;
+        const unsigned T = (p1 - p0 >= (4u << 20) && cnt >= 8) ? ZPK_SCATTER_THREADS : 1u;
+        if (T <= 1) part(ei, ej);
+        else {
+            std::thread th[ZPK_SCATTER_THREADS - 1];
+            for (unsigned t = 1; t < T; t++) th[t - 1] = std::thread(part, ei + cnt * t / T, ei + cnt * (t + 1) / T);
+            part(ei, ei + cnt / T);
+            for (unsigned t = 1; t < T; t++) th[t - 1].join();
         }
     }
     return ZPK_OK;
