@@ -30,3 +30,4 @@ for it in range(3):
     assert rc == 0 and all(x == 0 for x in results)
     print("pass %d: %d entries, %.2f GB compressed in, %.2f GB out, %.1f ms -> %.1f GiB/s decompressed (host pointers, PCIe inclusive)" % (it, n, len(arc) / 1e9, total / 1e9, dt * 1e3, total / dt / 2**30), flush=True)
 Z.close_reader(r)
+
