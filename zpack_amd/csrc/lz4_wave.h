@@ -138,116 +138,88 @@ __device__ __forceinline__ Lz4Tok lz4_token_at(const Lz4Bytes& B, u32 p, u32 C, 
     return t;
 }
 
-// The common shapes of a sequence — at most one length-extension byte on either side, everything inside
-// the staged chunk and strictly inside the block — evaluated from LDS without loops.  Returns false when
-// the general decoder (lz4_token_at) has to look at it; a divergent slow path costs every lane of the
-// wave, so the point is to keep ordinary long matches (ml >= 19) out of it.
+// The common shapes of a sequence — at most one length-extension byte on either side (literal runs below 270, matches
+// below 274), offset and extension byte before `lim` (the end of the staged bytes or of the block, whichever comes
+// first) — decoded WITHOUT a branch: three or four LDS reads and selects.  `slow` says the general decoder
+// (lz4_token_at) has to look at the sequence; then nothing else of the result means anything.  The kernel is bound by
+// instruction issue and by the scalar unit first (one per CU): a divergent `if` costs three scalar instructions per
+// level whether or not any lane takes it, and with 64 lanes some lane nearly always took the old slow path of a
+// 15-byte literal run.  Reads reach at most 275 bytes past the token: inside Lz4WaveShared for every token of a chunk.
+struct Lz4Quick { u32 lit_pos, lit, ml, next, off, slow; };
+// (predicates are 0/1 INTEGERS computed with shifts, not comparisons: a comparison result is a lane mask in scalar
+// registers and every `&&` / `||` of two of them is a scalar instruction; all values here are far below 2^31)
+__device__ __forceinline__ u32 lt31(u32 a, u32 b) { return (a - b) >> 31; }          // a < b
 template <bool FULL>
-__device__ __forceinline__ bool lz4_token_fast(const Lz4Bytes& B, u32 p, u32 C, u32 tok, Lz4Tok& t)
+__device__ __forceinline__ Lz4Quick lz4_quick(lds_cp8 S, u32 cbase, u32 p, u32 lim)
 {
-    const u32 lim = B.cend < C ? B.cend : C;       // bytes [p, lim) are staged and inside the block
-    u32 q = p + 1, lit = tok >> 4, ml = tok & 15;
-    bool ok = true;
-    if (lit == 15) {
-        if (q >= lim) return false;
-        const u32 b = lds_ld8(B.S + (q - B.cbase));
-        ok = b != 255; lit += b; q++;
-    }
-    t.lit_pos = q; t.lit = lit;
-    if (lit >= lim - q) return false;              // also keeps q + lit below any wrap
-    q += lit;
-    if (q + 3 > lim) return false;                 // room for the offset and one extension byte
-    if (FULL) t.off = lds_ld16(B.S + (q - B.cbase));
-    q += 2;
-    if (ml == 15) {
-        const u32 b = lds_ld8(B.S + (q - B.cbase));
-        ok = ok && b != 255; ml += b; q++;
-    }
-    t.ml = ml + 4; t.next = q; t.flags = 0;
-    return ok;
+    const lds_cp8 at = S + (p - cbase);
+    const u32 tok = lds_ld8(at), b1 = lds_ld8(at + 1);
+    const u32 lit4 = tok >> 4, mlc = tok & 15;
+    const u32 le = (lit4 + 1) >> 4, me = (mlc + 1) >> 4;          // 1 = a length-extension byte follows
+    const u32 lit = lit4 + (b1 & (0u - le));
+    const u32 q = 1 + le + lit;                                    // the offset field, relative to p
+    const u32 b2 = lds_ld8(at + q + 2);                            // first match-length extension byte, if there is one
+    Lz4Quick r;
+    r.off = FULL ? lds_ld16(at + q) : 0u;
+    r.lit_pos = p + 1 + le; r.lit = lit;
+    r.ml = mlc + 4 + (b2 & (0u - me));
+    r.next = p + q + 2 + me;
+    r.slow = (le & ((b1 + 1) >> 8)) | (me & ((b2 + 1) >> 8)) | lt31(lim, p + q + 3);
+    return r;
 }
 
-// Walk from `entry` while the token lies before seg_end.  The set of token positions visited (relative
-// to seg_start, < LZ4W_SEG <= 64) is kept as a bit mask; a re-walk from a new entry stops as soon as it
-// lands on a position the previous walk already visited — from there on the two chains are identical —
-// and inherits the tail.  flags (1 malformed, 2 last sequence of the block) always belong to a walk's
-// final hop, so they travel with the tail.  The number of sequences is the mask's population count.
+// Walk the token chain from `from` while the token lies before seg_end.  The set of token positions visited (relative
+// to seg_start, < LZ4W_SEG <= 64) is kept as a bit mask; a re-walk from a new entry stops as soon as it lands on a
+// position the previous walk already visited — from there on the two chains are identical — and inherits the tail.
+// flags (1 malformed, 2 last sequence of the block) always belong to a walk's final hop, so they travel with the tail.
+// The number of sequences is the mask's population count.
 //
-// INTERIOR = the block continues for at least LZ4W_SLACK staged bytes past the last token of the chunk:
-// a sequence with a short literal run (< 15) then needs no bounds check at all, and the hop is straight
-// -line code (two LDS reads, no exec-mask juggling) — the kernel is VALU/SALU-issue bound, and the hop is
-// its most executed piece.
+// RUN-IN: a speculative first walk starts at `from` < seg_start (inside the previous lane's segment) and records
+// nothing before seg_start.  A chain started at an arbitrary byte has usually joined the true chain after a segment's
+// worth of hops, so the position it enters the segment at (`entry`) is the true entry for ~96 % of the segments
+// (text) instead of ~0 % for "start at the segment boundary".  Anything odd on the way (end of block, malformed
+// parse) just restarts at seg_start.
+//
+// The loop is WAVE-UNIFORM: every lane runs the same instructions until no lane is live, per-lane state is selected,
+// not branched on (`on` = the lane takes part at all; the others get `old` back).  Only the rare general-decoder case
+// is a divergent branch.
 struct Lz4Walk { u32 exit, flags; u64 m; };
-template <bool INTERIOR>
-__device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, u32 entry, u32 seg_start, u32 seg_end, u32 C, const Lz4Walk& old)
+__device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, bool on, u32 from, u32 seg_start, u32 seg_end, u32 C,
+                                            const Lz4Walk& old, u32& entry_out)
 {
-    Lz4Walk w; w.flags = 0; w.m = 0;
-    u32 p = entry;
-    bool merged = false;
-    while (p < seg_end) {
-        const u32 r = p - seg_start;
-        if ((old.m >> r) & 1ull) { merged = true; break; }
-        w.m |= 1ull << r;
-        // tokens of a chunk always lie inside the staged range: one ds_read, no fallback
-        const lds_cp8 at = B.S + (p - B.cbase);
-        const u32 tok = lds_ld8(at);
-        u32 fl = 0, nx;
-        bool slow;
-        Lz4Tok t;
-        if (INTERIOR) {
-            const u32 lit = tok >> 4, ext = (tok & 15) == 15 ? 1u : 0u;
-            const u32 b = lds_ld8(at + 3 + lit);            // first match-length extension byte, if there is one
-            nx = p + 3 + lit + ext;
-            slow = lit == 15 || (ext && b == 255);
-        } else {
-            slow = !lz4_token_fast<false>(B, p, C, tok, t);
-            nx = t.next;
+    const u32 lim = B.cend < C ? B.cend : C;
+    u32 p = from, entry = from, live = on ? 1u : 0u, merged = 0, flags = 0, inseg, r;
+    u64 m = 0;
+    #define LZ4W_CHECK() do { live &= lt31(p, seg_end); inseg = lt31(p, seg_start) ^ 1u; r = (p - seg_start) & 63u; \
+                              const u32 hit = live & inseg & (u32)(old.m >> r); merged |= hit; live &= hit ^ 1u; } while (0)
+    LZ4W_CHECK();
+    while (__ballot(live != 0) != 0) {
+        m |= (u64)(live & inseg) << r;
+        const Lz4Quick t = lz4_quick<false>(B.S, B.cbase, live ? p : seg_start, lim);
+        u32 nx = t.next;
+        if (live & t.slow) {                                        // rare, divergent
+            const Lz4Tok tt = lz4_token_at(B, p, C, false);
+            nx = tt.next;
+            if (tt.flags) {
+                if (inseg) { flags |= tt.flags; live = 0; p = nx; }
+                else nx = seg_start;                                // an odd run-in gives up
+            }
         }
-        if (slow) {
-            if (!INTERIOR || !lz4_token_fast<false>(B, p, C, tok, t)) t = lz4_token_at(B, p, C, false);
-            fl = t.flags; nx = t.next;
-        }
-        w.flags |= fl;
-        p = nx;
-        if (fl) break;
+        entry = (live & (inseg ^ 1u)) ? nx : entry;                 // the newest position while still before the segment
+        p = live ? nx : p;
+        LZ4W_CHECK();
     }
-    w.exit = p;
+    #undef LZ4W_CHECK
+    Lz4Walk w; w.m = m; w.flags = flags; w.exit = p;
     if (merged) {
-        const u64 tail = old.m & ~((1ull << (p - seg_start)) - 1);
+        const u64 tail = old.m & ~((1ull << ((p - seg_start) & 63u)) - 1);
         w.m |= tail;
         w.flags |= old.flags;
         w.exit = old.exit;
     }
+    if (!on) w = old;
+    entry_out = entry;
     return w;
-}
-
-// Run-in of a speculative walk: hop from `p` (somewhere before seg_start) until the chain position reaches
-// seg_start, without recording anything.  A chain started at an arbitrary byte has usually joined the true
-// chain after a segment's worth of hops, so the position it enters the segment at is the true entry for ~96 %
-// of the segments (text) instead of ~0 % for "start at the segment boundary" — which turns the first, always
-// needed, all-lanes fix-up round into a check.  Anything odd (end of block, malformed parse) just gives up
-// and returns seg_start.
-template <bool INTERIOR>
-__device__ __forceinline__ u32 lz4_run_in(const Lz4Bytes& B, u32 p, u32 seg_start, u32 C)
-{
-    while (p < seg_start) {
-        const lds_cp8 at = B.S + (p - B.cbase);
-        const u32 tok = lds_ld8(at);
-        u32 nx; bool slow; Lz4Tok t;
-        if (INTERIOR) {
-            const u32 lit = tok >> 4, ext = (tok & 15) == 15 ? 1u : 0u;
-            const u32 b = lds_ld8(at + 3 + lit);
-            nx = p + 3 + lit + ext;
-            slow = lit == 15 || (ext && b == 255);
-        } else { slow = true; nx = p; }
-        if (slow) {
-            if (!lz4_token_fast<false>(B, p, C, tok, t)) t = lz4_token_at(B, p, C, false);
-            if (t.flags) return seg_start;
-            nx = t.next;
-        }
-        p = nx;
-    }
-    return p;
 }
 
 // one LZ4 block: src [ip, ip+C) -> dst [op, ...), cap = oend; dst_lo = lowest output address a match may reach
@@ -285,18 +257,15 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         u64 ts = SEQ_T(); (void)ts; SEQ_STAT(stt.t_stage += ts - tp0; stt.chunks++);
         Lz4Bytes B; B.S = to_lds(sh.stage); B.g = ip; B.cbase = cpos; B.cend = cpos + nst;
+        const u32 lim = B.cend < C ? B.cend : C;                   // sequences wholly before lim need no bounds checks
         // ---- walks to the fixed point ----
         const u32 my_start = cpos + (u32)lane * LZ4W_SEG;
         const u32 my_end = my_start + LZ4W_SEG < tok_end ? my_start + LZ4W_SEG : tok_end;
         const bool active = my_start < tok_end;
         u32 my_entry = my_start;
-        const bool interior = nst == LZ4W_CHUNK + LZ4W_SLACK;      // uniform: every chunk but the last of a block
         Lz4Walk w; w.exit = my_start; w.flags = 0; w.m = 0;
-        if (active && lane != 0) {                                 // lane 0 starts on the true chain
-            const u32 from = my_start - LZ4W_RUNIN;                // inside the previous lane's segment (lane >= 1)
-            my_entry = interior ? lz4_run_in<true>(B, from, my_start, C) : lz4_run_in<false>(B, from, my_start, C);
-        }
-        if (active) w = interior ? lz4_walk<true>(B, my_entry, my_start, my_end, C, w) : lz4_walk<false>(B, my_entry, my_start, my_end, C, w);
+        // lane 0 starts on the true chain, the others speculate from inside the previous lane's segment
+        w = lz4_walk(B, active, lane == 0 ? my_start : my_start - LZ4W_RUNIN, my_start, my_end, C, w, my_entry);
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_walk1 += t2 - ts; ts = t2; });
         for (int iter = 0; iter < 66; iter++) {
             SEQ_STAT(stt.fix_iters++);
@@ -304,10 +273,9 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             if (lane == 0) e = cpos;
             const bool changed = active && e != my_entry;
             if (__ballot(changed) == 0) break;
-            if (changed) {
-                my_entry = e;
-                w = interior ? lz4_walk<true>(B, my_entry, my_start, my_end, C, w) : lz4_walk<false>(B, my_entry, my_start, my_end, C, w);
-            }
+            u32 unused;
+            w = lz4_walk(B, changed, e, my_start, my_end, C, w, unused);       // e >= my_start: a predecessor's exit
+            my_entry = changed ? e : my_entry;
         }
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_fix += t2 - ts; ts = t2; });
         // inactive lanes forward the chain position
@@ -351,20 +319,13 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             if (lane < cnt) {
                 const u32 p = cpos + (u32)rec[sq % LZ4W_NREC];
                 tok_pos = p;
-                const lds_cp8 at = B.S + (p - B.cbase);
-                const u32 tok = lds_ld8(at);
-                const u32 lit = tok >> 4, mlc = tok & 15;
-                u32 o16 = 0, eb = 255;
-                if (interior) { o16 = lds_ld16(at + 1 + lit); eb = lds_ld8(at + 3 + lit); }   // unconditional: in range, maybe unused
-                Lz4Tok t;
-                if (interior && lit != 15 && !(mlc == 15 && eb == 255)) {            // straight-line common case
-                    q.lit = ip + p + 1; q.ll = lit; q.ml = mlc + 4 + (mlc == 15 ? eb : 0u); q.off = o16;
-                } else if (lz4_token_fast<true>(B, p, C, tok, t)) {                         // common case: 2-4 LDS reads in all
+                const Lz4Quick t = lz4_quick<true>(B.S, B.cbase, p, lim);
+                if (!t.slow) {                                                               // straight-line common case
                     q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
                 } else {
-                    t = lz4_token_at(B, p, C, true);
-                    q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
-                    if (t.flags & 1) q.bad = (t.flags & 4) ? 2u : 1u;
+                    const Lz4Tok tt = lz4_token_at(B, p, C, true);
+                    q.lit = ip + tt.lit_pos; q.ll = tt.lit; q.ml = tt.ml; q.off = tt.off;
+                    if (tt.flags & 1) q.bad = (tt.flags & 4) ? 2u : 1u;
                 }
                 // (a block holds at most 4 MiB of output: longer lengths only have to stay longer than that, and 64 of them
                 // must not wrap the 32-bit prefix sums)
@@ -378,7 +339,11 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             // executor assembles the batch there.  The first batch or two of a chunk find too little room and
             // take the direct path.
             const u32 dead = (u32)__builtin_amdgcn_readfirstlane((int)tok_pos) - cpos;
+#ifdef LZ4W_ABL_NOEXEC      // developer ablation (instruction counters only; the output is wrong): parse without the executor
+            (void)dead; const int rc = D_OK; { const u32 xx = wave_scan_add(q.ll + q.ml); op += (u32)__builtin_amdgcn_readlane((int)xx, 63); }
+#else
             const int rc = seq_exec_batch<true>(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
+#endif
             if (rc != D_OK) { op_io = op; return rc; }
         }
         if (fl) return D_MALFORMED;                                            // (not reached: the executor saw the malformed token)

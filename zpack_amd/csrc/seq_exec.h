@@ -310,8 +310,14 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
     // matches whose whole source is older than this batch go out together with the literals
     const bool early = has_match && !coop && src + (i64)need_len <= 0;
     SEQ_STAT({ u64 t1 = SEQ_T(); stt.t_dep += t1 - t0; t0 = t1; });
+#ifdef SEQ_ABL_NOCOPY       // developer ablation (instruction counters only; the output is wrong): positions + dependencies, no copies
+    if (__ballot(early && srcp == nullptr) == 0) { op += total; return D_OK; }
+#endif
 
     // ---- 3a. assembly in LDS ----
+#ifdef SEQ_ABL_NOASM         // developer ablation: every batch takes the direct path
+    asm_cap = 0;
+#endif
     if (lit_rle < 0 && total + (SEQ_ASM_PRE + SEQ_ASM_SLACK) <= (u64)asm_cap) {
         const bool straddle = has_match && !early && src < 0;                       // source begins before the batch, ends inside
         const u64 sm = __ballot(straddle);

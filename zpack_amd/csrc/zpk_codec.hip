@@ -101,7 +101,9 @@ __device__ __forceinline__ void finish_entry(const zpk_decode_desc& d, zpk_decod
     lane0_guard();
     if (status == R_OK) {                                                      // (ZPK_DF_SKIP_HASH: the hash is still produced, the status ignores it)
         wave_mem_fence();
+#ifndef ZPK_ABL_NOHASH       // (developer ablation: instruction counters without the hash pass)
         h = xxh3_64_wave(out, d.uncomp_size, lane);                            // lib/zpack_read.c:466
+#endif
         if (h != d.expect_hash && !(d.flags & ZPK_DF_SKIP_HASH)) status = R_FILE_HASH_MISMATCH;   // :467-468
     }
     lane0_guard();
@@ -354,7 +356,9 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(
         lane0_guard();
         if (ok) {
             wave_mem_fence();
-            h = xxh3_64_wave(out, d.uncomp_size, lane);                            // lib/zpack_read.c:466
+    #ifndef ZPK_ABL_NOHASH       // (developer ablation: instruction counters without the hash pass)
+        h = xxh3_64_wave(out, d.uncomp_size, lane);                            // lib/zpack_read.c:466
+#endif
             ok = h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH);
         }
         const int ok_status = R_OK;
