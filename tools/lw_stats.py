@@ -27,3 +27,8 @@ for k, v in zip(["parse", "literals", "deps", "rounds"], m[:4]):
     print("  %-9s %10.0f  %5.1f %%" % (k, v, 100 * v / m[6]))
 print("  other (stores, hash, frame) %.1f %%" % (100 * (m[6] - m[:4].sum()) / m[6]))
 print("  batches/entry %.1f rounds/entry %.1f" % ((a[:, 4] >> 32).mean(), (a[:, 4] & 0xFFFFFFFF).mean()))
+if os.environ.get("LW_PARSE"):      # a -DZPK_STATS_PARSE build: words 0..4 = stage / first walk / fix-up / emit / token fetch, 5 = hop iterations
+    ch = (a[:, 7] & 0xFFFFFFFF).astype(np.float64); fi = (a[:, 7] >> 32).astype(np.float64)
+    print("  parse phases (ticks/entry): stage %.0f walk1 %.0f fix %.0f emit %.0f tok %.0f" % tuple(m[:5]))
+    print("  chunks/entry %.2f fix rounds/chunk %.2f hop iterations per chunk: first walk %.1f, fix-up %.1f; slow-path iterations/chunk %.2f" % (
+        ch.mean(), fi.sum() / ch.sum(), (a[:, 5] >> 32).sum() / ch.sum(), (a[:, 5] & 0xFFFFFFFF).sum() / ch.sum(), a[:, 6].sum() / ch.sum()))

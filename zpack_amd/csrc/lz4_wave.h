@@ -184,41 +184,59 @@ __device__ __forceinline__ Lz4Quick lz4_quick(lds_cp8 S, u32 cbase, u32 p, u32 l
 // not branched on (`on` = the lane takes part at all; the others get `old` back).  Only the rare general-decoder case
 // is a divergent branch.
 struct Lz4Walk { u32 exit, flags; u64 m; };
+template <bool FIRST>
 __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, bool on, u32 from, u32 seg_start, u32 seg_end, u32 C,
-                                            const Lz4Walk& old, u32& entry_out)
+                                            const Lz4Walk& old, u32& entry_out, SeqStats& stt)
 {
+    (void)stt;
+    // positions relative to seg_start (negative = run-in); a lane that is not live keeps a position inside the staged
+    // chunk, so its (unused) LDS reads stay inside Lz4WaveShared; an exit far outside the chunk travels in exit_far
     const u32 lim = B.cend < C ? B.cend : C;
-    u32 p = from, entry = from, live = on ? 1u : 0u, merged = 0, flags = 0, inseg, r;
+    const i32 seg_len = (i32)(seg_end - seg_start), lim_rel = (i32)(lim - seg_start);
+    const lds_cp8 base = B.S + (seg_start - B.cbase);
+    i32 rp = (i32)(from - seg_start);
+    bool live = on, merged = false, far = false;
+    u32 flags = 0, exit_far = 0;
     u64 m = 0;
-    #define LZ4W_CHECK() do { live &= lt31(p, seg_end); inseg = lt31(p, seg_start) ^ 1u; r = (p - seg_start) & 63u; \
-                              const u32 hit = live & inseg & (u32)(old.m >> r); merged |= hit; live &= hit ^ 1u; } while (0)
-    LZ4W_CHECK();
-    while (__ballot(live != 0) != 0) {
-        m |= (u64)(live & inseg) << r;
-        const Lz4Quick t = lz4_quick<false>(B.S, B.cbase, live ? p : seg_start, lim);
-        u32 nx = t.next;
-        if (live & t.slow) {                                        // rare, divergent
-            const Lz4Tok tt = lz4_token_at(B, p, C, false);
-            nx = tt.next;
-            if (tt.flags) {
-                if (inseg) { flags |= tt.flags; live = 0; p = nx; }
-                else nx = seg_start;                                // an odd run-in gives up
-            }
+    for (;;) {
+        live = live && rp < seg_len;
+        const bool inseg = FIRST ? rp >= 0 : true;
+        if (!FIRST) {                                               // (a first walk has nothing to merge with)
+            const bool hit = live && ((u32)(old.m >> (rp & 63)) & 1u);
+            merged = merged || hit;
+            live = live && !hit;
         }
-        entry = (live & (inseg ^ 1u)) ? nx : entry;                 // the newest position while still before the segment
-        p = live ? nx : p;
-        LZ4W_CHECK();
+        if (__ballot(live) == 0) break;
+        SEQ_STAT(if (FIRST) stt.hops_first++; else stt.hops_fix++);
+        m |= (u64)((live && inseg) ? 1u : 0u) << (rp & 63);
+        // the common shapes, without a branch (see lz4_quick)
+        const lds_cp8 at = base + rp;
+        const u32 tok = lds_ld8(at), b1 = lds_ld8(at + 1);
+        const u32 lit4 = tok >> 4, mlc = tok & 15;
+        const bool l15 = lit4 == 15, m15 = mlc == 15;
+        const u32 q = lit4 + 1 + (l15 ? b1 + 1 : 0u);               // the offset field, relative to the token
+        const u32 b2 = lds_ld8(at + q + 2);
+        const i32 n2 = rp + (i32)q + 2;
+        i32 nx = n2 + (m15 ? 1 : 0);
+        const bool slow = (l15 && b1 == 255) || (m15 && b2 == 255) || n2 >= lim_rel;
+        if (live && slow) {                                         // rare, divergent
+            SEQ_STAT(stt.slow_hops++);
+            const Lz4Tok tt = lz4_token_at(B, seg_start + (u32)rp, C, false);
+            nx = (i32)(tt.next - seg_start);
+            if (tt.flags && !inseg) nx = 0;                         // an odd run-in gives up: walk from the segment boundary
+            else if (tt.flags || nx >= seg_len) { flags |= tt.flags; far = true; exit_far = tt.next; nx = seg_len; }
+        }
+        rp = live ? nx : rp;
     }
-    #undef LZ4W_CHECK
-    Lz4Walk w; w.m = m; w.flags = flags; w.exit = p;
+    Lz4Walk w; w.m = m; w.flags = flags; w.exit = far ? exit_far : seg_start + (u32)rp;
     if (merged) {
-        const u64 tail = old.m & ~((1ull << ((p - seg_start) & 63u)) - 1);
+        const u64 tail = old.m & ~((1ull << (rp & 63)) - 1);
         w.m |= tail;
         w.flags |= old.flags;
         w.exit = old.exit;
     }
     if (!on) w = old;
-    entry_out = entry;
+    entry_out = !FIRST ? from : m ? seg_start + (u32)__ffsll((long long)m) - 1u : w.exit;   // where the chain enters the segment
     return w;
 }
 
@@ -265,7 +283,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         u32 my_entry = my_start;
         Lz4Walk w; w.exit = my_start; w.flags = 0; w.m = 0;
         // lane 0 starts on the true chain, the others speculate from inside the previous lane's segment
-        w = lz4_walk(B, active, lane == 0 ? my_start : my_start - LZ4W_RUNIN, my_start, my_end, C, w, my_entry);
+        w = lz4_walk<true>(B, active, lane == 0 ? my_start : my_start - LZ4W_RUNIN, my_start, my_end, C, w, my_entry, stt);
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_walk1 += t2 - ts; ts = t2; });
         for (int iter = 0; iter < 66; iter++) {
             SEQ_STAT(stt.fix_iters++);
@@ -274,7 +292,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             const bool changed = active && e != my_entry;
             if (__ballot(changed) == 0) break;
             u32 unused;
-            w = lz4_walk(B, changed, e, my_start, my_end, C, w, unused);       // e >= my_start: a predecessor's exit
+            w = lz4_walk<false>(B, changed, e, my_start, my_end, C, w, unused, stt);       // e >= my_start: a predecessor's exit
             my_entry = changed ? e : my_entry;
         }
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_fix += t2 - ts; ts = t2; });

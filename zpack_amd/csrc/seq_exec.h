@@ -155,7 +155,7 @@ __device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
 // developer aid: cycle accounting of the executor (kept in registers; written out only when asked)
 // compiled in only with -DZPK_STATS (the counters cost ~10 registers, i.e. a wave of occupancy per SIMD)
 #ifdef ZPK_STATS
-struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; u64 t_stage, t_walk1, t_fix, t_emit, t_tok; u32 fix_iters, chunks, asm_batches; };
+struct SeqStats { u64 t_parse, t_lit, t_dep, t_rounds; u32 rounds, batches, coops, redirects; u64 t_stage, t_walk1, t_fix, t_emit, t_tok; u32 fix_iters, chunks, asm_batches, hops_first, hops_fix, slow_hops; };
 #define SEQ_T() __builtin_amdgcn_s_memtime()
 #define SEQ_STAT(x) do { x; } while (0)
 #else

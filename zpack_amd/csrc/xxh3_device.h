@@ -228,18 +228,24 @@ __device__ __forceinline__ u64 xxh3_64_wave(const u8* p, u64 len, int lane)
     st.init(lane);
     const u64 nblocks = (len - 1) >> 10;
     const u8* q = p + 16 * lane;
-    // software prefetch: two blocks' loads stay in flight while one is reduced (a block costs ~450 cycles of
-    // ALU, an L2/MALL round trip several thousand under load); deeper costs registers = occupancy
-    u128 r0 = {0, 0}, r1 = {0, 0};
-    if (nblocks > 0) r0 = ld128(q);
-    if (nblocks > 1) r1 = ld128(q + (1ull << 10));
-    for (u64 b = 0; b < nblocks; b += 2) {
-        u128 n0 = {0, 0}, n1 = {0, 0};
-        if (b + 2 < nblocks) n0 = ld128(q + ((b + 2) << 10));
-        if (b + 3 < nblocks) n1 = ld128(q + ((b + 3) << 10));
-        st.block(r0);
-        if (b + 1 < nblocks) st.block(r1);
-        r0 = n0; r1 = n1;
+    // Software prefetch, two pairs of blocks in turn: while one pair is reduced (a block costs ~60 vector instructions) the
+    // loads of the other are in flight.  The loads are UNCONDITIONAL (past the end they re-read the last block) and no loaded
+    // register is ever moved: the compiler counts outstanding loads exactly only then (s_waitcnt vmcnt(2)); with a guarded
+    // load or a register rotation it waits for everything, i.e. for the loads it has just issued — a full memory round trip
+    // per pair, which is what this loop used to cost (18 % of k_lz4_wave).
+    if (nblocks > 0) {
+        const u64 last = nblocks - 1;
+        #define XXH3_LD(i) ld128(q + (((i) < last ? (i) : last) << 10))
+        u128 a0 = XXH3_LD(0), a1 = XXH3_LD(1);
+        for (u64 b = 0; b < nblocks; b += 4) {
+            const u128 c0 = XXH3_LD(b + 2), c1 = XXH3_LD(b + 3);
+            st.block(a0);
+            if (b + 1 < nblocks) st.block(a1);
+            a0 = XXH3_LD(b + 4); a1 = XXH3_LD(b + 5);
+            if (b + 2 < nblocks) st.block(c0);
+            if (b + 3 < nblocks) st.block(c1);
+        }
+        #undef XXH3_LD
     }
     const u32 nstripes = (u32)(((len - 1) - (nblocks << 10)) >> 6);
     return st.finish(p + (nblocks << 10), nstripes, p + len, len, lane);

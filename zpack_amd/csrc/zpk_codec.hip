@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, 
             g[7] = ((u64)stt.fix_iters << 32) | stt.chunks;
 #ifdef ZPK_STATS_PARSE
             g[0] = stt.t_stage; g[1] = stt.t_walk1; g[2] = stt.t_fix; g[3] = stt.t_emit; g[4] = stt.t_tok;
+            g[5] = ((u64)stt.hops_first << 32) | stt.hops_fix; g[6] = stt.slow_hops;
 #endif
         }
 #else
