@@ -195,8 +195,8 @@ __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, bool on, u32 from
     const i32 seg_len = (i32)(seg_end - seg_start), lim_rel = (i32)(lim - seg_start);
     const lds_cp8 base = B.S + (seg_start - B.cbase);
     i32 rp = (i32)(from - seg_start);
-    bool live = on, merged = false, far = false;
-    u32 flags = 0, exit_far = 0;
+    bool live = on, merged = false;
+    u32 flags = 0, exit_far = 0, far = 0;
     u64 m = 0;
     for (;;) {
         live = live && rp < seg_len;
@@ -206,7 +206,7 @@ __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, bool on, u32 from
             merged = merged || hit;
             live = live && !hit;
         }
-        if (__ballot(live) == 0) break;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) break;
         SEQ_STAT(if (FIRST) stt.hops_first++; else stt.hops_fix++);
         m |= (u64)((live && inseg) ? 1u : 0u) << (rp & 63);
         // the common shapes, without a branch (see lz4_quick)
@@ -224,7 +224,7 @@ __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, bool on, u32 from
             const Lz4Tok tt = lz4_token_at(B, seg_start + (u32)rp, C, false);
             nx = (i32)(tt.next - seg_start);
             if (tt.flags && !inseg) nx = 0;                         // an odd run-in gives up: walk from the segment boundary
-            else if (tt.flags || nx >= seg_len) { flags |= tt.flags; far = true; exit_far = tt.next; nx = seg_len; }
+            else if (tt.flags || nx >= seg_len) { flags |= tt.flags; far = 1; exit_far = tt.next; nx = seg_len; }
         }
         rp = live ? nx : rp;
     }
