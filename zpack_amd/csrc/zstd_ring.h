@@ -106,6 +106,9 @@ __device__ inline int zr_block(ZstdRingShared& sh, ZFrameState& fs, LxOut& O, co
     else { if (left < 3) return LX_E_FRAME; nseq = (u64)uld8(p + 1) + ((u64)uld8(p + 2) << 8) + 0x7F00; left -= 3; }
     const u32 block_out = O.wp;
     u64 lit_pos = 0;
+#ifdef ZR_ABL_NOSEQ         // developer ablation (instruction counters only; the output is wrong): literals alone
+    if (nseq > 0) { fs.pre_idx += nseq; return LX_OK; }
+#endif
     if (nseq > 0) {
         if (left < 1) return LX_E_FRAME;
         const u64* const pre = fs.pre + fs.pre_idx;          // k_zstd_fse validated the tables and the bitstream of this block and decoded it
