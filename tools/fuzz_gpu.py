@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: a larger round of tests/test_gpu_codec.py::test_corrupted_frames_* — thousands of damaged frames per
 method / level in one device batch (XXH3 verify off), verdict + bytes against the oracle.  usage: fuzz_gpu.py [per_base] [seed] [lz4ring]
-(third argument "lz4ring": only the LZ4 configurations, through the opt-in ring path)"""
+(third argument "lz4ring": only the LZ4 configurations, through the opt-in ring path; "lz4": only the LZ4 configurations, general decoder)"""
 import os
 import sys
 import time
@@ -18,11 +18,12 @@ per = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 codec = zpack_amd.Codec(0)
 ring = len(sys.argv) > 3 and sys.argv[3] == "lz4ring"
+only_lz4 = ring or (len(sys.argv) > 3 and sys.argv[3] == "lz4")
 if ring:
     codec.set_option(zpack_amd.OPT_LZ4_RING, 1)
 o = oracle()
 dev = torch.device("cuda:0")
-for method, level in (((dg.LZ4, 0), (dg.LZ4, 9)) if ring else ((dg.ZSTD, 3), (dg.ZSTD, 1), (dg.ZSTD, 19), (dg.LZ4, 0), (dg.LZ4, 9))):
+for method, level in (((dg.LZ4, 0), (dg.LZ4, 9)) if only_lz4 else ((dg.ZSTD, 3), (dg.ZSTD, 1), (dg.ZSTD, 19), (dg.LZ4, 0), (dg.LZ4, 9))):
     rng = np.random.default_rng(seed * 100 + level + method)
     frames, sizes = [], []
     for cls, size in ((dg.TEXT, 300000), (dg.RECORDS, 70000), (dg.RUNS, 150000), (dg.TEXT, 9000), (dg.RANDOM, 20000), (dg.TEXT, 700)):
