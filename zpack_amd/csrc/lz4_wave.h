@@ -74,7 +74,7 @@ static_assert(LZ4W_SEG <= 64u, "the visited-position mask of a segment is one 64
 
 #ifndef LZ4W_NREC
 #define LZ4W_NREC 576u                           // token-position list: 9 batches of 64 sequences.  Measured: total LDS <= 5 KiB
-                                                 // per wave keeps 28 waves per CU (482 GiB/s); 5.5 KiB loses waves (451 GiB/s)
+                                                 // per wave keeps the waves the register budget allows (32 per CU at 64 VGPRs; 5.5 KiB loses waves: 451 vs 482 GiB/s in round 1)
 #endif
 struct alignas(16) Lz4WaveShared {
     u8  stage[LZ4W_CHUNK + LZ4W_SLACK + 16];     // + 16: literal runs are read 16 bytes at a time
@@ -283,7 +283,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
         u32 my_entry = my_start;
         Lz4Walk w; w.exit = my_start; w.flags = 0; w.m = 0;
         // lane 0 starts on the true chain, the others speculate from inside the previous lane's segment
-        w = lz4_walk<true>(B, active, lane == 0 ? my_start : my_start - LZ4W_RUNIN, my_start, my_end, C, w, my_entry, stt);
+        w = lz4_walk<true>(B, active, lane == 0 ? my_start : (my_start - cpos > LZ4W_RUNIN ? my_start - LZ4W_RUNIN : cpos), my_start, my_end, C, w, my_entry, stt);
         SEQ_STAT({ u64 t2 = SEQ_T(); stt.t_walk1 += t2 - ts; ts = t2; });
         for (int iter = 0; iter < 66; iter++) {
             SEQ_STAT(stt.fix_iters++);

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
     }
 }
 
-__global__ __launch_bounds__(64, 7) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
+__global__ __launch_bounds__(64, 8) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
                                                   const u32* __restrict__ counters, u64* __restrict__ dbg, int count_word)
