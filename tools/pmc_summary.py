@@ -16,7 +16,7 @@ def summarise(d):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("zpk::", "").strip()
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("zpk::", "").split("<")[0].strip()      # k_encode<12> and <14> are one kernel here
                 if not name.startswith("k_") and "zpk" not in name:
                     continue
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
