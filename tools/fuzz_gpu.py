@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer aid: a larger round of tests/test_gpu_codec.py::test_corrupted_frames_* — thousands of damaged frames per
-method / level in one device batch (XXH3 verify off), verdict + bytes against the oracle.  usage: fuzz_gpu.py [per_base] [seed] [lz4ring]
+method / level in one device batch (XXH3 verify off), verdict + bytes against the oracle.  usage: fuzz_gpu.py [per_base] [seed] [lz4ring|lz4|all] [level]
 (third argument "lz4ring": only the LZ4 configurations, through the opt-in ring path; "lz4": only the LZ4 configurations, general decoder)"""
 import os
 import sys
@@ -23,7 +23,10 @@ if ring:
     codec.set_option(zpack_amd.OPT_LZ4_RING, 1)
 o = oracle()
 dev = torch.device("cuda:0")
+only_level = int(sys.argv[4]) if len(sys.argv) > 4 else None
 for method, level in (((dg.LZ4, 0), (dg.LZ4, 9)) if only_lz4 else ((dg.ZSTD, 3), (dg.ZSTD, 1), (dg.ZSTD, 19), (dg.LZ4, 0), (dg.LZ4, 9))):
+    if only_level is not None and level != only_level:
+        continue
     rng = np.random.default_rng(seed * 100 + level + method)
     frames, sizes = [], []
     for cls, size in ((dg.TEXT, 300000), (dg.RECORDS, 70000), (dg.RUNS, 150000), (dg.TEXT, 9000), (dg.RANDOM, 20000), (dg.TEXT, 700)):

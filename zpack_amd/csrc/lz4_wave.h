@@ -142,14 +142,15 @@ __device__ __forceinline__ Lz4Tok lz4_token_at(const Lz4Bytes& B, u32 p, u32 C, 
 // below 274), offset and extension byte before `lim` (the end of the staged bytes or of the block, whichever comes
 // first) — decoded WITHOUT a branch: three or four LDS reads and selects.  `slow` says the general decoder
 // (lz4_token_at) has to look at the sequence; then nothing else of the result means anything.  The kernel is bound by
-// instruction issue and by the scalar unit first (one per CU): a divergent `if` costs three scalar instructions per
-// level whether or not any lane takes it, and with 64 lanes some lane nearly always took the old slow path of a
-// 15-byte literal run.  Reads reach at most 275 bytes past the token: inside Lz4WaveShared for every token of a chunk.
+// instruction issue — by the total number of instructions, scalar and vector: a divergent `if` costs
+// three scalar instructions per level whether or not any lane takes it, and with 64 lanes some lane nearly always took
+// the old slow path of a 15-byte literal run.  Reads reach at most 275 bytes past the token: inside Lz4WaveShared for
+// every token of a chunk.
 struct Lz4Quick { u32 lit_pos, lit, ml, next, off, slow; };
-// (predicates are 0/1 INTEGERS computed with shifts, not comparisons: a comparison result is a lane mask in scalar
-// registers and every `&&` / `||` of two of them is a scalar instruction; all values here are far below 2^31)
+// (here the predicates are 0/1 INTEGERS computed with shifts: a comparison result is a lane mask in scalar registers and
+// every `&&` / `||` of two of them is a scalar instruction.  lz4_walk below keeps lane masks instead — there the mask
+// arithmetic replaces about as many vector instructions, measured equal; all values are far below 2^31)
 __device__ __forceinline__ u32 lt31(u32 a, u32 b) { return (a - b) >> 31; }          // a < b
-template <bool FULL>
 __device__ __forceinline__ Lz4Quick lz4_quick(lds_cp8 S, u32 cbase, u32 p, u32 lim)
 {
     const lds_cp8 at = S + (p - cbase);
@@ -160,7 +161,7 @@ __device__ __forceinline__ Lz4Quick lz4_quick(lds_cp8 S, u32 cbase, u32 p, u32 l
     const u32 q = 1 + le + lit;                                    // the offset field, relative to p
     const u32 b2 = lds_ld8(at + q + 2);                            // first match-length extension byte, if there is one
     Lz4Quick r;
-    r.off = FULL ? lds_ld16(at + q) : 0u;
+    r.off = lds_ld16(at + q);
     r.lit_pos = p + 1 + le; r.lit = lit;
     r.ml = mlc + 4 + (b2 & (0u - me));
     r.next = p + q + 2 + me;
@@ -337,7 +338,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
             if (lane < cnt) {
                 const u32 p = cpos + (u32)rec[sq % LZ4W_NREC];
                 tok_pos = p;
-                const Lz4Quick t = lz4_quick<true>(B.S, B.cbase, p, lim);
+                const Lz4Quick t = lz4_quick(B.S, B.cbase, p, lim);
                 if (!t.slow) {                                                               // straight-line common case
                     q.lit = ip + t.lit_pos; q.ll = t.lit; q.ml = t.ml; q.off = t.off;
                 } else {
