@@ -9,6 +9,6 @@ import sys,json
 for l in sys.stdin:
     try: d=json.loads(l)
     except Exception: continue
-    print('%-14s'%'$n', 'GiB/s %.1f'%d['value'], 'ms/step %.3f'%d['ms_per_step'], 'stage_ms', [round(x,3) for x in d['roofline']['stage_ms']], 'ring', d['decode_stats']['lz4_ring'], 'parity', d['parity']['xxh3_equal_real_xxhash'])
+    print('%-14s'%'$n', 'GiB/s %.1f'%d['value'], 'ms/step %.3f'%d['ms_per_step'], 'stage_ms', [round(x,3) for x in d['roofline']['stage_ms']], 'ratio', d['config'].get('comp_ratio'), 'parity', d['parity'].get('all_ranks'))
 "
 done | tee gpurun_out/abl_run.txt
