@@ -191,13 +191,15 @@ __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, bool on, u32 from
 {
     (void)stt;
     // positions relative to seg_start (negative = run-in); a lane that is not live keeps a position inside the staged
-    // chunk, so its (unused) LDS reads stay inside Lz4WaveShared; an exit far outside the chunk travels in exit_far
+    // chunk, so its (unused) LDS reads stay inside Lz4WaveShared; an exit far outside the chunk travels in exit_far —
+    // also that of a chain which enters beyond the segment (a long literal run or match jumped over it): nothing to walk
     const u32 lim = B.cend < C ? B.cend : C;
     const i32 seg_len = (i32)(seg_end - seg_start), lim_rel = (i32)(lim - seg_start);
     const lds_cp8 base = B.S + (seg_start - B.cbase);
-    i32 rp = (i32)(from - seg_start);
-    bool live = on, merged = false;
-    u32 flags = 0, exit_far = 0, far = 0;
+    const bool start_in = on && (i32)(from - seg_start) < seg_len;
+    i32 rp = start_in ? (i32)(from - seg_start) : seg_len;
+    bool live = start_in, merged = false;
+    u32 flags = 0, exit_far = from, far = on && !start_in ? 1u : 0u;
     u64 m = 0;
     for (;;) {
         live = live && rp < seg_len;
