@@ -119,3 +119,57 @@ if __name__ == "__main__":
     for runin in ([int(sys.argv[3])] if len(sys.argv) > 3 else [60, 120]):
         for v in ("neigh", "skip", "max"):
             run(mix, n, runin, v)
+
+
+def run_table(mix, n, K):
+    """Alternative scheme (not built): no run-in; every lane walks the chains from EACH of its first K positions (a walk stops where it
+    meets a position already visited), so that it knows the exit for any entry among its visited positions; the true chain is then
+    resolved lane by lane with table look-ups.  Reports the wave iterations (max over lanes of the hops) and how often the true entry
+    is not in a lane's table (those lanes still need a walk)."""
+    b = dg.Batch(n, 65536, 65536, method=dg.LZ4, level=0, seed=1, mix=mix)
+    chunks = its = miss = lanes_n = extra = 0
+    for i in range(n):
+        fr = b.archive[int(b.offsets[i]):int(b.offsets[i]) + int(b.comp_sizes[i])]
+        for blk in blocks_of(fr):
+            d = blk.tolist(); C = len(d); cpos = 0
+            while cpos < C:
+                tok_end = min(C, cpos + CHUNK)
+                tabs = []; mx = 0
+                for l in range(NL):
+                    s = cpos + l * SEG
+                    if s >= tok_end: break
+                    e = min(s + SEG, tok_end)
+                    exit_of = {}; hops = 0
+                    for st in range(s, min(s + K, e)):
+                        path = []; p = st
+                        while p < e and p not in exit_of:
+                            path.append(p); hops += 1
+                            nx, fl = hop(d, C, p)
+                            p = nx
+                            if fl: break
+                        ex = exit_of[p] if p in exit_of else p
+                        for q in path: exit_of[q] = ex
+                    tabs.append((s, e, exit_of)); mx = max(mx, hops)
+                its += mx; chunks += 1; lanes_n += len(tabs)
+                # resolve the true chain
+                p = cpos; fix = 0
+                for (s, e, exit_of) in tabs:
+                    if p >= e: continue
+                    if p in exit_of: p = exit_of[p]
+                    else:
+                        miss += 1
+                        while p < e and p not in exit_of:
+                            fix += 1
+                            nx, fl = hop(d, C, p); p = nx
+                            if fl: break
+                        if p in exit_of: p = exit_of[p]
+                extra += fix
+                assert p > cpos
+                cpos = p
+    print("mix %d table K=%2d: chunks %d  walk its/chunk %.1f  lanes whose true entry is not in the table %.2f %%  serial fix hops/chunk %.1f" % (
+        mix, K, chunks, its / chunks, 100.0 * miss / lanes_n, extra / chunks))
+
+
+if __name__ == "__main__" and len(sys.argv) > 4 and sys.argv[4] == "table":
+    for K in (8, 16, 24):
+        run_table(int(sys.argv[1]), int(sys.argv[2]), K)
