@@ -8,8 +8,14 @@ Default workload = BASELINE.json configs[1]: 100k x 64 KiB LZ4-frame entries (lz
 text/records/random/runs mix, frames produced by the real liblz4 with the reference writer's call sequence).
 
   python bench.py --gpus N --steps K --warmup W [--workload ...] [--scaling weak|strong]
-  (N > 1: launched by torch.distributed.run, one rank per GPU; the only communication is the barrier, the max-reduce of the
-   timing and — strong scaling — the gather of the per-entry results on rank 0: entries are independent)
+  N > 1: one rank per GPU.  Either launched by torch.distributed.run (WORLD_SIZE set: this process IS a rank), or started
+  plainly — then this process, BEFORE it touches torch / HIP, starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+  as a CHILD process, relays its JSON line and exit code and exits (never an exec from a process that has initialised the GPU).
+  On a box with fewer than N GPUs (the 1-GPU development box) the ranks share cuda:0 over gloo ("rehearsal": RCCL refuses two
+  ranks on one device; at most 4 ranks) and the line says so in `config`.  The only communication is the barrier, the
+  max-reduce of the timing and — strong scaling — the gather of the per-entry results on rank 0: entries are independent,
+  there is no data-path collective.  Default scaling: strong for c4_mixed (ONE archive, static shard by
+  bytes, zpack_amd/shard.py), weak for the others (one batch per rank).
 
 Prints ONE JSON line (rank 0).  `value` = bytes of all ranks / max-over-ranks wall time of the K timed steps (barrier +
 synchronize on both sides).  `roofline` is for the dominant kernel(s), timed with HIP events on the launch stream inside the last
@@ -146,14 +152,65 @@ def pmc_traffic(workload, n, knames, sha):
     return dict(traffic=None, fetch_raw=None, write=None, low=None, note=note)
 
 
+def _visible_gpus():
+    """number of HIP devices WITHOUT initialising the runtime in this process (the parent only spawns)"""
+    n = 0
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for d in os.listdir(base):
+            try:
+                props = dict(l.split()[:2] for l in open(os.path.join(base, d, "properties")) if len(l.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except OSError:
+                pass
+    except OSError:
+        pass
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if vis is not None and vis.strip() != "":
+        n = min(n, len([x for x in vis.split(",") if x.strip() != ""])) if n else len([x for x in vis.split(",") if x.strip() != ""])
+    return n
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start N ranks as a child torch.distributed.run, relay its output and exit code"""
+    import socket
+    import subprocess
+    have = _visible_gpus()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if have < n:
+        if n > 4:
+            print("bench.py: --gpus %d asked for, %d GPU(s) visible: a rehearsal on one card is limited to 4 ranks" % (n, have), file=sys.stderr)
+            return 2
+        env["ZPK_BENCH_REHEARSAL"] = "1"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in p.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return p.returncode if p.returncode != 0 or line is not None else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2_lz4_64k", choices=sorted(WORKLOADS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank decodes its own batch; strong: ONE archive, statically sharded by bytes over the ranks")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: every rank decodes its own batch; strong: ONE archive, statically sharded by bytes over the ranks "
+                         "(default: strong for c4_mixed, weak otherwise)")
     ap.add_argument("--entries", type=int, default=0, help="override the entry count (debug; the line then names it)")
     ap.add_argument("--mix", type=int, default=-1, help="-1 = 70/20/5/5 class mix, 0..3 = single class")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
@@ -161,6 +218,13 @@ def main():
     ap.add_argument("--lz4-ring", action="store_true", help="LZ4 entries through the scan + LDS-ring executor first (ZPK_OPT_LZ4_RING)")
     ap.add_argument("--skip-hash", action="store_true", help="diagnostic only: status ignores the XXH3 verdict (the line says so)")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.workload == "c4_mixed" else "weak"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])              # nothing above has touched torch or HIP
+    if args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+        return 2
 
     import numpy as np
     import torch
@@ -283,6 +347,8 @@ def main():
         kern = "lz4_ring" if (w["kernel"] == "lz4" and args.lz4_ring) else w["kernel"]
         kids = dict(lz4=[zpack_amd.K_LZ4], lz4_ring=[zpack_amd.K_LZ4_SCAN, zpack_amd.K_LZ4], zstd=[zpack_amd.K_ZSTD_FSE, zpack_amd.K_ZSTD],
                     stored=[zpack_amd.K_STORED])[kern]
+        if w["method"] < 0:                                     # mixed batch: the LZ4 kernel runs too, its time explains ms_per_step
+            kids = [zpack_amd.K_LZ4] + kids
         stage_ms = [codec.kernel_ms(k) for k in kids] if n else [0.0]      # the LAST timed launch's kernels
         codec.set_profiling(False)
         dstats = codec.decode_stats()
@@ -344,7 +410,9 @@ def main():
                            "class_mix": "70/20/5/5 text/records/random/runs" if args.mix < 0 else ["text", "records", "random", "runs"][args.mix],
                            "comp_ratio": total_comp / max(total_uncomp, 1.0),
                            "parallelism": ("one archive, static shard by bytes (zpack_amd/shard.py), results gathered on rank 0" if strong
-                                           else "one batch per rank") + ", no data-path collective",
+                                           else "one batch per rank") + ", no data-path collective"
+                                          + ("; REHEARSAL: all %d ranks share cuda:0 over gloo (fewer GPUs than ranks on this box)" % world if rehearsal else ""),
+                           "rehearsal_one_card": rehearsal,
                            "lz4_path": "scan + ring executor, general decoder behind it" if args.lz4_ring else "general decoder",
                            "frames_by": "liblz4/libzstd of the image, reference writer call sequence", "gen_seconds": round(t_gen, 1)},
                 "parity": {"all_status_ok": bad == 0, "xxh3_equal_real_xxhash": hash_ok, "sizes_equal": size_ok,
@@ -355,8 +423,11 @@ def main():
                              "copy_ceiling_source": "k_stored (copy + XXH3 fused) of this build on a 1 GiB stored batch, read + write bytes / "
                                                     "HIP-event time, same process",
                              "traffic": tr["traffic"], "traffic_fetch_raw": tr["fetch_raw"], "traffic_write": tr["write"],
-                             "traffic_source": tr["note"], "csrc_sha1": sha, "kernel": "+".join(KNAMES[kern]),
-                             "kernel_ms": k_ms, "stage_ms": stage_ms, "kernel_ms_source": "HIP events around the kernels of the last timed step",
+                             "traffic_source": tr["note"], "csrc_sha1": sha,
+                             "kernel": "+".join((["k_lz4_wave"] if w["method"] < 0 else []) + KNAMES[kern]),
+                             "kernel_ms": k_ms, "stage_ms": stage_ms,
+                             "stage_names": (["k_lz4_wave"] if w["method"] < 0 else []) + {"lz4": ["k_lz4_wave"], "lz4_ring": ["lz4 scan stages", "k_lz4_exec+k_lz4_wave"],
+                                             "zstd": ["k_zstd_fse", "k_zstd_exec+k_zstd"], "stored": ["k_stored"]}[kern], "kernel_ms_source": "HIP events around the kernels of the last timed step",
                              "algorithmic_bytes_per_launch": alg_bytes},
                 "decode_stats": dstats,
                 "cpu_baseline": cpu,
@@ -442,7 +513,9 @@ def main():
                            "level": level, "class_mix": "70/20/5/5 text/records/random/runs" if args.mix < 0 else ["text", "records", "random", "runs"][args.mix],
                            "comp_ratio": total_comp / total_src, "reference_ratio": (cpu or {}).get("ratio"),
                            "timed": "zpk_codec_encode_batch_device + zpk_codec_pack_batch_device (size scan + compaction = write_offset += comp_size)",
-                           "parallelism": "one batch per rank, no data-path collective", "gen_seconds": round(t_gen, 1)},
+                           "parallelism": "one batch per rank, no data-path collective"
+                                          + ("; REHEARSAL: all %d ranks share cuda:0 over gloo" % world if rehearsal else ""),
+                           "rehearsal_one_card": rehearsal, "gen_seconds": round(t_gen, 1)},
                 "parity": {"all_status_ok": ok_status, "gpu_decoder_round_trip_bytes_and_xxh3": rt_ok, "xxh3_equal_real_xxhash_sample": hash_ok,
                            "oracle_decodes_sample": orc_ok, "all_ranks": parity},
                 "event_ms_per_step": ev_ms / args.steps,

@@ -169,7 +169,27 @@ def test_write_archive_oneshot_and_streaming(Z, golden_dir, tmp_path, method, le
     assert arc2 == arc                                           # same container either way
 
 
-@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 3), (METHOD_NONE, 0)])
+def test_c5_config_zstd1_one_mib_sources(Z):
+    """BASELINE.json configs[4] in small: zpack_write_files of 1 MiB sources at Zstandard level 1 (16 linked 64 KiB blocks per entry:
+    k_encode<12> with matches across blocks), every corpus class; frames decoded by the oracle, the compiled reference and the GPU."""
+    want = [("c5_%d_%d" % (cls, k), dg.fill(cls, 4, 100 * cls + k, 1 << 20).tobytes()) for cls in range(4) for k in range(3)]
+    arc = Z.write_archive(want, METHOD_ZSTD, 1)
+    _decode_all_with_checkers(arc, want)
+    ents = zpk.parse(arc)
+    by_class = {}
+    for e, (n, d) in zip(ents, want):
+        by_class.setdefault(int(n.split("_")[1]), []).append(e["comp_size"] / len(d))
+    assert max(by_class[dg.TEXT]) < 0.40 and max(by_class[dg.RECORDS]) < 0.60 and max(by_class[dg.RUNS]) < 0.05, by_class
+    assert max(by_class[dg.RANDOM]) < 1.001                          # raw blocks: never larger than the frame overhead
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    for i, (n, d) in enumerate(want):
+        rc, out = Z.read_file(r, i, len(d))
+        assert rc == 0 and out[:len(d)] == d, (n, rc)
+    Z.lib.zpack_close_reader(C.byref(r))
+
+
+@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 3), (METHOD_ZSTD, 1), (METHOD_NONE, 0)])
 def test_batch_write_then_batch_read_roundtrip(Z, method, level):
     """zpack_write_files (n files, one device batch) then the additive zpack_read_files / _packed."""
     rng = np.random.default_rng(5)

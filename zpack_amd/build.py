@@ -19,11 +19,32 @@ ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
 ARCH = "gfx950"
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+def _digest(sources, extra=""):
+    """identity of a target's inputs: file names + contents (+ the flags); mtimes do not survive a push to a fresh box"""
+    import hashlib
+    h = hashlib.sha1(extra.encode())
+    for s in sorted(sources):
+        if s.endswith(".so"):                     # a linked-against library: its own stamp stands for it
+            s = s + ".stamp" if os.path.exists(s + ".stamp") else s
+        h.update(os.path.basename(s).encode())
+        with open(s, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stale(target, sources, extra=""):
+    """True when the target is missing or was built from other inputs than the ones present (stamp file next to it)"""
+    want = _digest(sources, extra)
+    try:
+        have = open(target + ".stamp").read().strip()
+    except OSError:
+        have = None
+    return want if (have != want or not os.path.exists(target)) else None
+
+
+def _stamp(target, digest):
+    with open(target + ".stamp", "w") as fh:
+        fh.write(digest + "\n")
 
 
 def _hipcc():
@@ -35,8 +56,11 @@ def _hipcc():
 
 def build_codec(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "zpack_codec.h")]
-    if not force and not _newer(CODEC_SO, srcs):
+    flags = (os.environ.get("ZPK_STATS") or "") + "|" + os.environ.get("ZPK_DEFINES", "")
+    dig = _stale(CODEC_SO, srcs, flags)
+    if not force and dig is None:
         return CODEC_SO
+    dig = dig or _digest(srcs, flags)
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-function", "-o", CODEC_SO, os.path.join(CSRC, "zpk_codec.hip")]
     if os.environ.get("ZPK_STATS"):          # developer build: per-phase cycle counters in the decode kernels
@@ -46,6 +70,7 @@ def build_codec(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _stamp(CODEC_SO, dig)
     return CODEC_SO
 
 
@@ -53,14 +78,17 @@ def build_zpack(force=False, verbose=False):
     host = os.path.join(HERE, "host")
     csrcs = sorted(os.path.join(host, f) for f in os.listdir(host) if f.endswith(".c"))
     deps = csrcs + [os.path.join(ROOT, "include", "zpack.h"), os.path.join(ROOT, "include", "zpack_codec.h"), CODEC_SO]
-    if not force and not _newer(ZPACK_SO, deps):
+    dig = _stale(ZPACK_SO, deps)
+    if not force and dig is None:
         return ZPACK_SO
+    dig = dig or _digest(deps)
     cmd = ["gcc", "-O2", "-g", "-fPIC", "-shared", "-std=c11", "-Wall", "-Wextra", "-D_FILE_OFFSET_BITS=64", "-D_POSIX_C_SOURCE=200809L", "-fvisibility=hidden",
            "-I" + os.path.join(ROOT, "include"), "-o", ZPACK_SO] + csrcs + \
           ["-L" + HERE, "-lzpk_codec", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _stamp(ZPACK_SO, dig)
     return ZPACK_SO
 
 
@@ -68,13 +96,17 @@ def build_programs(force=False, verbose=False):
     """zpack_amd/zpk-batch: the batch-aware `t` / `x` commands over libzpack_amd.so (programs/zpk_batch.c)"""
     src = os.path.join(HERE, "programs", "zpk_batch.c")
     exe = os.path.join(HERE, "zpk-batch")
-    if not force and not _newer(exe, [src, ZPACK_SO, os.path.join(ROOT, "include", "zpack.h")]):
+    deps = [src, ZPACK_SO, os.path.join(ROOT, "include", "zpack.h")]
+    dig = _stale(exe, deps)
+    if not force and dig is None:
         return exe
+    dig = dig or _digest(deps)
     cmd = ["gcc", "-O2", "-g", "-std=c11", "-Wall", "-Wextra", "-D_FILE_OFFSET_BITS=64", "-I" + os.path.join(ROOT, "include"), "-o", exe, src,
            "-L" + HERE, "-lzpack_amd", "-lzpk_codec", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _stamp(exe, dig)
     return exe
 
 
