@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from benchdata import datagen as dg
 
-SEG, NL = 60, 64
+SEG, NL = int(os.environ.get("SIM_SEG", "60")), 64
 CHUNK = SEG * NL
 
 def blocks_of(frame):
