@@ -39,7 +39,29 @@
     X(28, "v_pk_add_u16", "v_pk_add_u16 %0, %0, %1\n v_pk_add_u16 %1, %1, %2\n v_pk_add_u16 %2, %2, %3\n v_pk_add_u16 %3, %3, %0") \
     X(29, "v_max_u32 / v_min_u32", "v_max_u32 %0, %0, %1\n v_min_u32 %1, %1, %2\n v_max_u32 %2, %2, %3\n v_min_u32 %3, %3, %0") \
     X(30, "v_max3_u32", "v_max3_u32 %0, %0, %1, %2\n v_max3_u32 %1, %1, %2, %3\n v_max3_u32 %2, %2, %3, %0\n v_max3_u32 %3, %3, %0, %1") \
-    X(31, "v_mul_hi_u32", "v_mul_hi_u32 %0, %0, %1\n v_mul_hi_u32 %1, %1, %2\n v_mul_hi_u32 %2, %2, %3\n v_mul_hi_u32 %3, %3, %0")
+    X(31, "v_mul_hi_u32", "v_mul_hi_u32 %0, %0, %1\n v_mul_hi_u32 %1, %1, %2\n v_mul_hi_u32 %2, %2, %3\n v_mul_hi_u32 %3, %3, %0") \
+    X(32, "v_or_b32", "v_or_b32 %0, %0, %1\n v_or_b32 %1, %1, %2\n v_or_b32 %2, %2, %3\n v_or_b32 %3, %3, %0") \
+    X(33, "v_xor_b32", "v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %0") \
+    X(34, "v_sub_u32", "v_sub_u32 %0, %0, %1\n v_sub_u32 %1, %1, %2\n v_sub_u32 %2, %2, %3\n v_sub_u32 %3, %3, %0") \
+    X(35, "v_mov_b32", "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0") \
+    X(36, "v_cndmask_b32 (vcc fixed)", "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc") \
+    X(37, "v_cmp_lt_u32 vcc", "v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %0") \
+    X(38, "v_lshrrev_b32", "v_lshrrev_b32 %0, %1, %0\n v_lshrrev_b32 %1, %2, %1\n v_lshrrev_b32 %2, %3, %2\n v_lshrrev_b32 %3, %0, %3") \
+    X(39, "v_lshrrev_b32 by constant", "v_lshrrev_b32 %0, 4, %1\n v_lshrrev_b32 %1, 4, %2\n v_lshrrev_b32 %2, 4, %3\n v_lshrrev_b32 %3, 4, %0") \
+    X(40, "v_lshl_or_b32", "v_lshl_or_b32 %0, %0, 2, %1\n v_lshl_or_b32 %1, %1, 2, %2\n v_lshl_or_b32 %2, %2, 2, %3\n v_lshl_or_b32 %3, %3, 2, %0") \
+    X(41, "v_add_co_u32 (carry out only)", "v_add_co_u32 %0, vcc, %0, %1\n v_add_co_u32 %1, vcc, %1, %2\n v_add_co_u32 %2, vcc, %2, %3\n v_add_co_u32 %3, vcc, %3, %0") \
+    X(42, "v_addc_co_u32", "v_addc_co_u32 %0, vcc, %0, %1, vcc\n v_addc_co_u32 %1, vcc, %1, %2, vcc\n v_addc_co_u32 %2, vcc, %2, %3, vcc\n v_addc_co_u32 %3, vcc, %3, %0, vcc") \
+    X(43, "v_lshl_add_u64", "v_lshl_add_u64 %4, %4, 0, %5\n v_lshl_add_u64 %5, %5, 0, %4\n v_lshl_add_u64 %4, %4, 0, %5\n v_lshl_add_u64 %5, %5, 0, %4") \
+    X(44, "v_mad_u64_u32", "v_mad_u64_u32 %4, vcc, %0, %1, %4\n v_mad_u64_u32 %5, vcc, %2, %3, %5\n v_mad_u64_u32 %4, vcc, %1, %2, %4\n v_mad_u64_u32 %5, vcc, %3, %0, %5") \
+    X(45, "v_not_b32", "v_not_b32 %0, %1\n v_not_b32 %1, %2\n v_not_b32 %2, %3\n v_not_b32 %3, %0") \
+    X(46, "v_and_b32 with literal constant", "v_and_b32 %0, 0xff00ff, %1\n v_and_b32 %1, 0xff00ff, %2\n v_and_b32 %2, 0xff00ff, %3\n v_and_b32 %3, 0xff00ff, %0") \
+    X(47, "v_add_u32 e64 (sgpr operand)", "v_add_u32 %0, s10, %1\n v_add_u32 %1, s11, %2\n v_add_u32 %2, s12, %3\n v_add_u32 %3, s13, %0") \
+    X(48, "v_mov_b64", "v_mov_b64 %4, %5\n v_mov_b64 %5, %4\n v_mov_b64 %4, %5\n v_mov_b64 %5, %4") \
+    X(49, "v_ashrrev_i32", "v_ashrrev_i32 %0, 3, %1\n v_ashrrev_i32 %1, 3, %2\n v_ashrrev_i32 %2, 3, %3\n v_ashrrev_i32 %3, 3, %0") \
+    X(50, "v_subrev_u32 / v_sub_co", "v_subrev_u32 %0, %0, %1\n v_subrev_u32 %1, %1, %2\n v_subrev_u32 %2, %2, %3\n v_subrev_u32 %3, %3, %0") \
+    X(51, "v_pk_add_u16 / pk ops", "v_pk_lshlrev_b16 %0, 1, %1\n v_pk_lshlrev_b16 %1, 1, %2\n v_pk_lshlrev_b16 %2, 1, %3\n v_pk_lshlrev_b16 %3, 1, %0") \
+    X(52, "v_cmp_eq_u32 to sgpr pair", "v_cmp_eq_u32 s[10:11], %0, %1\n v_cmp_eq_u32 s[12:13], %1, %2\n v_cmp_eq_u32 s[14:15], %2, %3\n v_cmp_eq_u32 s[10:11], %3, %0") \
+    X(53, "v_cndmask_b32 e64 (sgpr pair mask)", "v_cndmask_b32 %0, %0, %1, s[10:11]\n v_cndmask_b32 %1, %1, %2, s[12:13]\n v_cndmask_b32 %2, %2, %3, s[14:15]\n v_cndmask_b32 %3, %3, %0, s[10:11]")
 
 template <int MODE>
 __global__ __launch_bounds__(64, 8) void k(uint32_t* out, int iters, uint32_t seed)
