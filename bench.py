@@ -45,7 +45,7 @@ WORKLOADS = {
     # encode: BASELINE.json configs[4] per GPU (100k x 1 MiB over 8 GPUs = 12 500 per GPU), Zstandard level 1 + XXH3
     "c5_zstd1_1m": dict(kind="encode", n=12500, lo=1 << 20, hi=1 << 20, method=1, level=1, seed=4, kernel="encode"),
 }
-KNAMES = {"lz4": ["k_lz4_wave"], "lz4_ring": ["k_lz4_frames", "k_lz4_scan", "k_lz4_seam", "k_lz4_exec", "k_lz4_wave"],
+KNAMES = {"lz4": ["k_lz4_wave"],
           "zstd": ["k_zstd_fse", "k_zstd_exec", "k_zstd"], "stored": ["k_stored"], "encode": ["k_encode"]}
 
 
@@ -215,7 +215,6 @@ def main():
     ap.add_argument("--mix", type=int, default=-1, help="-1 = 70/20/5/5 class mix, 0..3 = single class")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--lz4-ring", action="store_true", help="LZ4 entries through the scan + LDS-ring executor first (ZPK_OPT_LZ4_RING)")
     ap.add_argument("--skip-hash", action="store_true", help="diagnostic only: status ignores the XXH3 verdict (the line says so)")
     args = ap.parse_args()
     if args.scaling is None:
@@ -258,8 +257,6 @@ def main():
     ncores = len(os.sched_getaffinity(0))
     gen_threads = max(1, ncores // max(1, world))
     codec = zpack_amd.Codec(local_rank)
-    if args.lz4_ring:
-        codec.set_option(zpack_amd.OPT_LZ4_RING, 1)
     stream = torch.cuda.current_stream().cuda_stream
     sha = csrc_sha1()
     red_dev = torch.device("cpu") if rehearsal else dev
@@ -344,9 +341,8 @@ def main():
             codec.decode_batch_device(src, ddesc, n, dst, dres, stream)
 
         wall, ev_ms = timed(step)
-        kern = "lz4_ring" if (w["kernel"] == "lz4" and args.lz4_ring) else w["kernel"]
-        kids = dict(lz4=[zpack_amd.K_LZ4], lz4_ring=[zpack_amd.K_LZ4_SCAN, zpack_amd.K_LZ4], zstd=[zpack_amd.K_ZSTD_FSE, zpack_amd.K_ZSTD],
-                    stored=[zpack_amd.K_STORED])[kern]
+        kern = w["kernel"]
+        kids = dict(lz4=[zpack_amd.K_LZ4], zstd=[zpack_amd.K_ZSTD_FSE, zpack_amd.K_ZSTD], stored=[zpack_amd.K_STORED])[kern]
         if w["method"] < 0:                                     # mixed batch: the LZ4 kernel runs too, its time explains ms_per_step
             kids = [zpack_amd.K_LZ4] + kids
         stage_ms = [codec.kernel_ms(k) for k in kids] if n else [0.0]      # the LAST timed launch's kernels
@@ -413,7 +409,6 @@ def main():
                                            else "one batch per rank") + ", no data-path collective"
                                           + ("; REHEARSAL: all %d ranks share cuda:0 over gloo (fewer GPUs than ranks on this box)" % world if rehearsal else ""),
                            "rehearsal_one_card": rehearsal,
-                           "lz4_path": "scan + ring executor, general decoder behind it" if args.lz4_ring else "general decoder",
                            "frames_by": "liblz4/libzstd of the image, reference writer call sequence", "gen_seconds": round(t_gen, 1)},
                 "parity": {"all_status_ok": bad == 0, "xxh3_equal_real_xxhash": hash_ok, "sizes_equal": size_ok,
                            "bytes_equal_oracle_sample": bytes_ok, "all_ranks": parity},
@@ -426,7 +421,7 @@ def main():
                              "traffic_source": tr["note"], "csrc_sha1": sha,
                              "kernel": "+".join((["k_lz4_wave"] if w["method"] < 0 else []) + KNAMES[kern]),
                              "kernel_ms": k_ms, "stage_ms": stage_ms,
-                             "stage_names": (["k_lz4_wave"] if w["method"] < 0 else []) + {"lz4": ["k_lz4_wave"], "lz4_ring": ["lz4 scan stages", "k_lz4_exec+k_lz4_wave"],
+                             "stage_names": (["k_lz4_wave"] if w["method"] < 0 else []) + {"lz4": ["k_lz4_wave"],
                                              "zstd": ["k_zstd_fse", "k_zstd_exec+k_zstd"], "stored": ["k_stored"]}[kern], "kernel_ms_source": "HIP events around the kernels of the last timed step",
                              "algorithmic_bytes_per_launch": alg_bytes},
                 "decode_stats": dstats,

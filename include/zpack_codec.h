@@ -74,8 +74,7 @@ typedef struct zpk_decode_desc {
 } zpk_decode_desc;
 
 #define ZPK_DF_SKIP_HASH 1u    /* decode only; results[i].hash is still produced, status ignores it */
-#define ZPK_DF_GENERAL   2u    /* keep this entry off the fast LZ4 path (lz4_ring.h): the general decoder takes it.  Same results by
-                                  contract — the parity tests decode every batch both ways */
+#define ZPK_DF_GENERAL   2u    /* accepted and ignored (round 2 used it to keep an entry off an opt-in LZ4 path that no longer exists) */
 
 typedef struct zpk_decode_result {
     int32_t  status;           /* enum zpack_result */
@@ -109,10 +108,8 @@ void        zpk_codec_destroy(zpk_codec* c);
 void        zpk_codec_reset(zpk_codec* c);                  /* after an abandoned stream / error */
 const char* zpk_codec_last_error(const zpk_codec* c);
 int         zpk_codec_device(const zpk_codec* c);
-/* options.  ZPK_OPT_LZ4_RING (default 0): put the token scan + LDS-ring executor (lz4_ring.h) in front of the general LZ4 decoder.  Same
- * results by contract (the general decoder finishes whatever the ring path declines); on MI355X it is not yet the faster of the two
- * on the 64 KiB batch, so it is opt-in. */
-enum { ZPK_OPT_LZ4_RING = 1 };
+/* options: none at present — every call returns ZPK_E_INVALID (round 2's ZPK_OPT_LZ4_RING path lost to the default decoder on every
+ * corpus class and was removed in round 3; the entry point stays so that the ABI does not shrink) */
 int         zpk_codec_set_option(zpk_codec* c, int option, int value);
 
 /* ---- batch decode + verify ----------------------------------------------------------------
@@ -164,13 +161,9 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
 /* per-kernel timing of decode batches: when enabled, every decode batch brackets each of its kernels
  * with HIP events on the launch stream; zpk_codec_kernel_ms then returns the duration of kernel
  * `which` (ZPK_K_*) in the most recent batch (synchronises on that batch). */
-enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2 /* k_lz4_exec + k_lz4_wave */, ZPK_K_ZSTD = 3, ZPK_K_ZSTD_FSE = 4, ZPK_K_PACK = 5,
-       ZPK_K_LZ4_SCAN = 6, ZPK_K_ENCODE = 7, ZPK_K_COUNT = 8 };
+enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2 /* k_lz4_wave */, ZPK_K_ZSTD = 3 /* k_zstd_exec + k_zstd */, ZPK_K_ZSTD_FSE = 4,
+       ZPK_K_PACK = 5, ZPK_K_RESERVED6 = 6, ZPK_K_ENCODE = 7, ZPK_K_COUNT = 8 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
-/* zpk_codec_decode_stats2: out[0] = LZ4 entries finished by the ring path, out[1] = left to the general decoder, out[2..10] = the
- * leftovers by reason (0 not a plain frame, then LX_E_* of lz4_ring.h), out[11] a unit could not be listed, out[12] a seam did not
- * join, out[13] scan units */
-int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16]);
 /* counters of the most recent decode batch (synchronises): out[0..2] = entries on the stored / zstd / lz4 work
  * lists, out[3] = Zstandard entries finished on pre-decoded sequences (two-stage path), out[4] = by the fused decoder,
  * out[5], out[6] = entries / waves the pre-decode kernel gave up on (watchdog; expected 0) */

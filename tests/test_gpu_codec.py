@@ -337,38 +337,25 @@ def _run_device_batch(codec, b, flags):
 
 @pytest.mark.parametrize("mix,size,n", [(-1, 65536, 384), (dg.TEXT, 65536, 128), (dg.RECORDS, 65536, 128), (dg.RUNS, 65536, 64),
                                         (dg.RANDOM, 65536, 64), (-1, (1000, 300000), 300), (dg.TEXT, 1 << 20, 12), (dg.TEXT, (1, 400), 300)])
-def test_lz4_ring_path_vs_general_decoder_and_oracle(codec, mix, size, n):
-    """The fast LZ4 path (token scan -> ring executor, lz4_ring.h) against the general decoder (ZPK_DF_GENERAL) and the oracle,
-    XXH3 verify OFF so that nothing but the bytes decides: same status, size, hash and bytes either way, every byte equal to the
-    oracle's; the counters must show that the friendly classes really finished on the ring path, and no byte outside an entry's
-    own slot range [dst_offset, dst_offset + produced) may have been touched."""
+def test_lz4_decoder_shapes_vs_oracle(codec, mix, size, n):
+    """k_lz4_wave on eight batch shapes (every corpus class at 64 KiB, ragged sizes from 1 byte to 1 MiB), XXH3 verify OFF so that
+    nothing but the bytes decides: status, size and hash of every entry, every byte of every entry equal to the oracle's, and no
+    byte outside an entry's own slot range [dst_offset, dst_offset + produced) may have been touched."""
     o = oracle()
     lo, hi = size if isinstance(size, tuple) else (size, size)
     b = dg.Batch(n, lo, hi, method=dg.LZ4, level=0, seed=23, mix=mix)
-    codec.set_option(zpack_amd.OPT_LZ4_RING, 1)
-    try:
-        desc, r_ring, out_ring, st_ring = _run_device_batch(codec, b, zpack_amd.DF_SKIP_HASH)
-        _, r_gen, out_gen, st_gen = _run_device_batch(codec, b, zpack_amd.DF_SKIP_HASH | zpack_amd.DF_GENERAL)
-    finally:
-        codec.set_option(zpack_amd.OPT_LZ4_RING, 0)
-    assert st_gen["lz4_ring"] == 0 and st_gen["lz4_general"] == n, st_gen
-    assert st_ring["lz4_ring"] + st_ring["lz4_general"] == n, st_ring
-    assert (r_ring["status"] == 0).all() and (r_gen["status"] == 0).all(), (r_ring[r_ring["status"] != 0][:3], r_gen[r_gen["status"] != 0][:3])
-    assert np.array_equal(r_ring["produced"], b.uncomp_sizes) and np.array_equal(r_gen["produced"], b.uncomp_sizes)
-    assert np.array_equal(r_ring["hash"], b.hashes), np.nonzero(r_ring["hash"] != b.hashes)[0][:10]
-    assert np.array_equal(r_gen["hash"], b.hashes)
+    desc, r, out, st = _run_device_batch(codec, b, zpack_amd.DF_SKIP_HASH)
+    assert st["lz4"] == n, st
+    assert (r["status"] == 0).all(), r[r["status"] != 0][:3]
+    assert np.array_equal(r["produced"], b.uncomp_sizes)
+    assert np.array_equal(r["hash"], b.hashes), np.nonzero(r["hash"] != b.hashes)[0][:10]
     arc = b.archive.tobytes()
     for i in range(n):
         d = desc[i]
         a, k = int(d["dst_offset"]), int(d["uncomp_size"])
-        got = out_ring[a:a + k]
-        if not np.array_equal(got, out_gen[a:a + k]) or i % 16 == 0:
-            rc, want, _, _ = o.entry_decode(arc, int(d["src_offset"]), int(d["comp_size"]), k, int(d["expect_hash"]), 2, k)
-            w = np.frombuffer(want, dtype=np.uint8)[:k]
-            bad = np.nonzero(got != w)[0]
-            assert rc == 0 and bad.size == 0, (i, "class", int(b.classes[i]), "first bad byte", int(bad[0]) if bad.size else -1, "of", k)
-        nxt = int(desc[i + 1]["dst_offset"]) if i + 1 < n else len(out_ring) - 64
-        assert (out_ring[a + k:nxt] == 0xA5).all(), ("bytes past the entry were written", i)
-    if mix in (-1, dg.TEXT, dg.RECORDS, dg.RANDOM) and lo >= 65536:
-        friendly = n if mix != -1 else int((b.classes != dg.RUNS).sum())
-        assert st_ring["lz4_ring"] >= friendly - 2, "ring %d general %d why %s" % (st_ring["lz4_ring"], st_ring["lz4_general"], st_ring["lz4_general_why"])   # runs entries (long matches) belong to the general decoder
+        rc, want, _, _ = o.entry_decode(arc, int(d["src_offset"]), int(d["comp_size"]), k, int(d["expect_hash"]), 2, k)
+        w = np.frombuffer(want, dtype=np.uint8)[:k]
+        bad = np.nonzero(out[a:a + k] != w)[0]
+        assert rc == 0 and bad.size == 0, (i, "class", int(b.classes[i]), "first bad byte", int(bad[0]) if bad.size else -1, "of", k)
+        nxt = int(desc[i + 1]["dst_offset"]) if i + 1 < n else len(out) - 64
+        assert (out[a + k:nxt] == 0xA5).all(), ("bytes past the entry were written", i)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: a larger round of tests/test_gpu_codec.py::test_corrupted_frames_* — thousands of damaged frames per
-method / level in one device batch (XXH3 verify off), verdict + bytes against the oracle.  usage: fuzz_gpu.py [per_base] [seed] [lz4ring|lz4|all] [level]
-(third argument "lz4ring": only the LZ4 configurations, through the opt-in ring path; "lz4": only the LZ4 configurations, general decoder)"""
+method / level in one device batch (XXH3 verify off), verdict + bytes against the oracle.  usage: fuzz_gpu.py [per_base] [seed] [lz4|all] [level]
+(third argument "lz4": only the LZ4 configurations)"""
 import os
 import sys
 import time
@@ -17,10 +17,7 @@ from tests._libs import oracle
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 codec = zpack_amd.Codec(0)
-ring = len(sys.argv) > 3 and sys.argv[3] == "lz4ring"
-only_lz4 = ring or (len(sys.argv) > 3 and sys.argv[3] == "lz4")
-if ring:
-    codec.set_option(zpack_amd.OPT_LZ4_RING, 1)
+only_lz4 = len(sys.argv) > 3 and sys.argv[3] == "lz4"
 o = oracle()
 dev = torch.device("cuda:0")
 only_level = int(sys.argv[4]) if len(sys.argv) > 4 else None

@@ -12,7 +12,6 @@ except Exception as e: print('   (no line)', e)
 for a in "$@"; do
   case $a in
     c2) run bench_c2 --steps 10 --warmup 3;;
-    c2ring) run bench_c2_ring --steps 5 --warmup 2 --lz4-ring --no-cpu;;
     c3) run bench_c3 --workload c3_zstd_256k --steps 5 --warmup 2;;
     c4) run bench_c4 --workload c4_mixed --steps 5 --warmup 2;;
     c5small) run bench_c5_small --workload c5_zstd1_1m --entries 1500 --steps 3 --warmup 1 --cpu-seconds 8;;

@@ -11,7 +11,6 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smok
 timeout -k 10 900 python bench.py > $out/${tag}_c2_lz4_bench.json 2> $out/c2.err; echo "bench c2 rc=$?"
 trace c2_lz4 --steps 10 --warmup 3
 pmc2 c2 c2_lz4_64k 100000
-timeout -k 10 900 python bench.py --lz4-ring --steps 5 --warmup 2 --no-cpu > $out/${tag}_c2_lz4_ring_bench.json 2> $out/c2ring.err; echo "bench c2 ring rc=$?"
 timeout -k 10 900 python bench.py --workload c3_zstd_256k --steps 3 --warmup 1 > $out/${tag}_c3_zstd_bench.json 2> $out/c3.err; echo "bench c3 rc=$?"
 trace c3_zstd --workload c3_zstd_256k --steps 3 --warmup 1
 pmc2 c3 c3_zstd_256k 100000 --workload c3_zstd_256k
@@ -19,7 +18,7 @@ timeout -k 10 900 python bench.py --workload c4_mixed --steps 3 --warmup 1 > $ou
 timeout -k 10 1100 python bench.py --workload c5_zstd1_1m --steps 3 --warmup 1 > $out/${tag}_c5_zstd1_bench.json 2> $out/c5.err; echo "bench c5 rc=$?"
 trace c5_zstd1 --workload c5_zstd1_1m --entries 4000 --steps 2 --warmup 1
 ZPK_BENCH_REHEARSAL=1 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 2 --workload c4_mixed --entries 30000 --scaling strong --steps 3 --warmup 1 > $out/${tag}_c4_strong_2rank_rehearsal.json 2> $out/strong.err; echo "strong2 rc=$?"
-for f in c2_lz4 c2_lz4_ring c3_zstd c4_mixed c5_zstd1; do python3 - <<PY
+for f in c2_lz4 c3_zstd c4_mixed c5_zstd1; do python3 - <<PY
 import json
 try:
     d=json.loads(open("$out/${tag}_${f}_bench.json").read().strip().splitlines()[-1]); r=d["roofline"]; c=d.get("cpu_baseline") or {}

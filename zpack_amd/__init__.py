@@ -17,8 +17,7 @@ ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
 METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
 DF_GENERAL = 2
-OPT_LZ4_RING = 1
-K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_LZ4_SCAN, K_ENCODE = 0, 1, 2, 3, 4, 5, 6, 7
+K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_ENCODE = 0, 1, 2, 3, 4, 5, 7
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
 DECODE_DESC = np.dtype([("src_offset", "<u8"), ("comp_size", "<u8"), ("uncomp_size", "<u8"), ("expect_hash", "<u8"),
@@ -148,12 +147,8 @@ class Codec:
         """Counters of the last decode batch: entries per method and how the Zstandard ones were finished."""
         a = (C.c_uint32 * 8)()
         self._chk(self.L.zpk_codec_decode_stats(self.h, a), "decode_stats")
-        b = (C.c_uint32 * 16)()
-        self.L.zpk_codec_decode_stats2.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
-        self._chk(self.L.zpk_codec_decode_stats2(self.h, b), "decode_stats2")
         return dict(stored=a[0], zstd=a[1], lz4=a[2], zstd_two_stage=a[3], zstd_fused=a[4], fse_watchdog=a[5], fse_budget=a[6],
-                    lz4_ring=b[0], lz4_general=b[1], lz4_general_why=[b[2 + i] for i in range(11)], lz4_units=b[13],
-                    zstd_arena_refused=bool(a[7] >> 31), lz4_lists_refused=bool((a[7] >> 30) & 1))
+                    zstd_arena_refused=bool(a[7] >> 31))
 
     def debug_fetch(self, what, offset, count, dtype):
         a = np.zeros(count, dtype=dtype)

@@ -23,7 +23,7 @@
 #include "zpk_device.h"
 #include "xxh3_device.h"
 #include "lz4_wave.h"
-#include "lz4_ring.h"
+#include "lx_ring.h"
 #ifndef LX_WAVES_PER_SIMD
 #define LX_WAVES_PER_SIMD 6
 #endif
@@ -36,12 +36,7 @@ using namespace zpk;
 // counters layout (u32): [0..3] count per work list, [4..7] dequeue head per list
 enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4, N_LISTS = 3 };
 // [8] dequeue head of k_zstd_fse, [9] Zstandard entries finished on pre-decoded sequences, [10] finished by the fused decoder
-enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT = 17,
-       C_LZ4_LEFT = 18,        // LZ4 entries the ring path left to the general decoder
-       C_LZ4_RING = 19,        // LZ4 entries finished by the ring path
-       C_LZ4_WHY = 20,         // [20..28]: leftovers by anomaly code (LX_E_*; slot 0 = not listed by the scan)
-       C_LZ4_UNITS = 29,       // scan units appended by k_lz4_frames
-       N_COUNTERS = 32 };
+enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT = 17, N_COUNTERS = 32 };
 
 // ------------------------------------------------------------------------------------ kernels
 
@@ -167,7 +162,7 @@ __global__ __launch_bounds__(64, 8) void k_lz4_wave(const u8* __restrict__ src, 
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
                                                   const u32* __restrict__ counters, u64* __restrict__ dbg, int count_word)
 {
-    // `list` / counters[count_word]: the LZ4 work list itself, or what the ring path (k_lz4_exec) left over
+    // `list` / counters[count_word]: the LZ4 work list
     const int lane = lane_id();
     __shared__ Lz4WaveShared shw;
     u32 idx;
@@ -200,90 +195,6 @@ __global__ __launch_bounds__(64, 8) void k_lz4_wave(const u8* __restrict__ src, 
         else if (o.rc == D_TRUNCATED) status = o.produced < d.dst_capacity ? R_FILE_INCOMPLETE : R_BUFFER_TOO_SMALL;
         else if (o.rc == D_DST_FULL) status = R_BUFFER_TOO_SMALL;
         finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
-    }
-}
-
-// ---- the LZ4 ring path (lz4_ring.h): frame walk, one LANE per entry: verdict "plain frame" + the units of its compressed blocks ... ----
-__global__ __launch_bounds__(64) void k_lz4_frames(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
-                                                   const zpk_decode_desc* __restrict__ desc, const u32* __restrict__ list,
-                                                   u32* __restrict__ counters, u32* __restrict__ meta, Lz4Unit* __restrict__ units, u32 unit_cap)
-{
-    const int lane = lane_id();
-    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 nl = uni(counters[L_LZ4]);
-    if ((u64)blockIdx.x * blockDim.x >= nl) return;
-    const bool live = idx < nl;
-    u32 e = 0;
-    zpk_decode_desc d; memset(&d, 0, sizeof(d));
-    if (live) { e = list[idx]; d = desc[e]; }
-    // (the walk reads through `src + offset`; read_lo/read_hi bound what is really there — the host path stages a sub-range)
-    const bool want = live && src + d.src_offset >= read_lo && !(d.flags & ZPK_DF_GENERAL);
-    const u32 ok = lz4_frames_wave(src, (u64)(read_hi - src), d.src_offset, want ? d.comp_size : 0, e, units, &counters[C_LZ4_UNITS], unit_cap, lane);
-    if (live) meta[e] = ok;
-}
-
-// ... token scan, one LANE per unit (one LX_SEG-byte segment of one compressed block) ...
-__global__ __launch_bounds__(64) void k_lz4_scan(const u8* __restrict__ src, const u8* read_hi, const u32* __restrict__ counters,
-                                                 const Lz4Unit* __restrict__ units, u8* __restrict__ tok, u32* __restrict__ meta, u64* __restrict__ dbg)
-{
-    const int lane = lane_id();
-    __shared__ Lz4ScanShared shs;
-    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 nu = uni(counters[C_LZ4_UNITS]);
-    if ((u64)blockIdx.x * blockDim.x >= nu) return;
-    Lz4Unit u; u.blk = 0; u.bsz_seg = 0; u.entry = 0;
-    if (idx < nu) u = units[idx];
-    const bool ok = lz4_scan_units(shs, src, (u64)(read_hi - src), u.blk, u.bsz_seg & 0xFFFFFu, u.bsz_seg >> 20, tok, lane,
-                                   dbg && blockIdx.x < 1024 ? dbg + 8 * blockIdx.x : nullptr);
-    if (idx < nu && !ok) meta[u.entry] = 2u;                  // not listed: a unit of it could not be
-}
-
-// ... seam repair, one LANE per unit: the chain across the seam behind the unit becomes exact ...
-__global__ __launch_bounds__(64) void k_lz4_seam(const u8* __restrict__ src, const u32* __restrict__ counters,
-                                                 const Lz4Unit* __restrict__ units, u8* __restrict__ tok, u32* __restrict__ meta)
-{
-    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= counters[C_LZ4_UNITS]) return;
-    const Lz4Unit u = units[idx];
-    if (meta[u.entry] != 1u) return;                          // (already given up: its lists may be incomplete)
-    if (!lz4_seam(src, u.blk, u.bsz_seg & 0xFFFFFu, u.bsz_seg >> 20, tok)) meta[u.entry] = 3u;    // a seam did not join
-}
-
-// ... then one WAVE per entry executes the listed sequences; whatever it does not finish goes on the leftover list
-__global__ __launch_bounds__(64, LX_WAVES_PER_SIMD) void k_lz4_exec(const u8* __restrict__ src, const u8* read_hi,
-                                                    const zpk_decode_desc* __restrict__ desc, u8* dst,
-                                                    zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
-                                                    u32* __restrict__ counters, const u8* __restrict__ tok,
-                                                    const u32* __restrict__ meta, u32* __restrict__ leftover, u64* __restrict__ dbg)
-{
-    const int lane = lane_id();
-    __shared__ Lz4ExecShared shx;
-    u32 idx;
-    if (!my_slot(counters, L_LZ4, idx)) return;
-    const u32 e = uni(list[idx]);
-    const zpk_decode_desc d = desc[e];
-    const u32 verdict = uni(meta[e]);
-    int why = verdict == 2u ? 30 - C_LZ4_WHY : (verdict == 3u ? 31 - C_LZ4_WHY : 0);
-    bool finished = false;
-    if (verdict == 1u) {
-        const LxResult r = lz4f_exec_wave(shx, src, read_hi, uni64(d.src_offset), uni64(d.comp_size), tok, uni_ptr(dst + d.dst_offset),
-                                          uni64(d.dst_capacity), uni64(d.uncomp_size), lane, dbg ? dbg + (u64)e * 16 : nullptr);
-        why = r.rc;
-        if (r.rc == LX_OK) {
-            finished = true;
-            lane0_guard();
-            if (lane == 0) {
-                zpk_decode_result o; o.detail = 0; o.produced = r.produced; o.hash = r.hash;
-                o.status = (d.flags & ZPK_DF_SKIP_HASH) || r.hash == d.expect_hash ? R_OK : R_FILE_HASH_MISMATCH;     // lib/zpack_read.c:466-468
-                res[e] = o;
-                atomicAdd(&counters[C_LZ4_RING], 1u);
-            }
-        }
-    }
-    lane0_guard();
-    if (!finished && lane == 0) {
-        leftover[atomicAdd(&counters[C_LZ4_LEFT], 1u)] = e;
-        atomicAdd(&counters[C_LZ4_WHY + (why < 0 || why > 11 || why == 9 ? 0 : why)], 1u);     // (slot 9 is C_LZ4_UNITS; 10, 11 = scan / seam)
     }
 }
 
@@ -483,12 +394,7 @@ struct zpk_codec {
     u8*  d_packoff = nullptr;    u64 packoff_cap = 0;  // host encode path: payload offsets
     u64* d_zarena = nullptr;     u64 zarena_cap = 0;   // decoder: pre-decoded Zstandard sequences, laid out like dst (zstd_fse4.h)
     u32* d_zstate = nullptr;     u64 zstate_cap = 0;   // decoder: per entry, 1 = its sequences are in the arena
-    u8*  d_tok = nullptr;        u64 tok_cap = 0;      // decoder: LZ4 token lists, laid out like 3/4 of src (lz4_ring.h)
-    u32* d_lz4meta = nullptr;    u64 lz4meta_cap = 0;  // decoder: per entry scan verdict [n] + the ring path's leftover list [n]
-    void* d_units = nullptr;     u64 units_cap = 0;    // decoder: scan units (lz4_ring.h)
     int lz4_hint = -1;           // host path: does the batch hold an LZ4 entry?  -1 = unknown (device path)
-    int lz4_general_only = 0;    // the last decode batch could not get its token scratch: general LZ4 decoder only
-    int opt_lz4_ring = 0;        // ZPK_OPT_LZ4_RING: scan + ring executor in front of the general LZ4 decoder (lz4_ring.h)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t kev[ZPK_K_COUNT][2] = {};
     int profiling = 0;
@@ -575,7 +481,7 @@ void zpk_codec_destroy(zpk_codec* c)
     (void)hipFree(c->d_counters); (void)hipFree(c->d_lists); (void)hipFree(c->d_lit);
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
     for (int k = 0; k < 2; k++) { if (c->h_pin[k]) (void)hipHostFree(c->h_pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
-    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_tok); (void)hipFree(c->d_lz4meta); (void)hipFree(c->d_units); (void)hipFree(c->d_pack); (void)hipFree(c->d_packed); (void)hipFree(c->d_packoff);
+    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_pack); (void)hipFree(c->d_packed); (void)hipFree(c->d_packoff);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
@@ -642,42 +548,12 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     if (!(skip & 1)) hipLaunchKernelGGL(k_stored, dim3(wgrid), dim3(256), 0, st, src, desc, dst, res, c->d_lists + L_NONE * stride, c->d_counters);
     ZPK_KEV(ZPK_K_STORED, 1);
     ZPK_TRACE_STEP("k_stored");
-    // LZ4: token scan (one lane per entry) -> ring executor (one wave per entry) -> the general decoder for whatever those two
-    // did not finish (lz4_ring.h).  Without the token scratch the general decoder takes the whole list.
+    // LZ4: one wave per work-list slot (lz4_wave.h)
     const bool maybe_lz4 = c->lz4_hint != 0;
-    bool ring = maybe_lz4 && c->opt_lz4_ring;
-    ZPK_DEV(static const int lz4_general = getenv("ZPK_LZ4_GENERAL") ? atoi(getenv("ZPK_LZ4_GENERAL")) : 0; if (lz4_general) ring = false;)
-    c->lz4_general_only = 0;
-    const u64 src_bytes = (u64)(read_hi - read_lo);
-    // units: a block of a plain frame holds 64 KiB of output (the last one less), so blocks <= dst_size / 64 KiB + n; an entry whose
-    // frame is cut into more, smaller blocks than that finds the unit list full and goes to the general decoder
-    const u64 unit_cap = src_bytes / LX_SEG + dst_size / 65536 + 2 * n + 64;
-    if (ring && (unit_cap > 0xFFFFFFF0ull ||
-                 grow(c, (void**)&c->d_tok, &c->tok_cap, ((u64)(read_hi - src) * 3) / 4 + 256) != ZPK_OK ||
-                 grow(c, (void**)&c->d_lz4meta, &c->lz4meta_cap, 2 * n * sizeof(u32)) != ZPK_OK ||
-                 grow(c, &c->d_units, &c->units_cap, unit_cap * sizeof(Lz4Unit)) != ZPK_OK)) {
-        ring = false; c->lz4_general_only = 1;
-        snprintf(c->err, sizeof(c->err), "note: no memory for the LZ4 token lists; this batch ran the general LZ4 decoder");
-    }
-    ZPK_KEV(ZPK_K_LZ4_SCAN, 0);
-    if (!(skip & 2) && ring) {
-        hipLaunchKernelGGL(k_lz4_frames, dim3((u32)((n + 63) / 64)), dim3(64), 0, st, src, read_lo, read_hi, desc,
-                           c->d_lists + L_LZ4 * stride, c->d_counters, c->d_lz4meta, (Lz4Unit*)c->d_units, (u32)unit_cap);
-        hipLaunchKernelGGL(k_lz4_scan, dim3((u32)((unit_cap + 63) / 64)), dim3(64), 0, st, src, read_hi, c->d_counters,
-                           (const Lz4Unit*)c->d_units, c->d_tok, c->d_lz4meta, c->d_dbg);
-        hipLaunchKernelGGL(k_lz4_seam, dim3((u32)((unit_cap + 63) / 64)), dim3(64), 0, st, src, c->d_counters,
-                           (const Lz4Unit*)c->d_units, c->d_tok, c->d_lz4meta);
-    }
-    ZPK_KEV(ZPK_K_LZ4_SCAN, 1);
-    ZPK_TRACE_STEP("k_lz4_scan");
     ZPK_KEV(ZPK_K_LZ4, 0);
-    if (!(skip & 2) && ring)
-        hipLaunchKernelGGL(k_lz4_exec, dim3((u32)n), dim3(64), 0, st, src, read_hi, desc, dst, res, c->d_lists + L_LZ4 * stride,
-                           c->d_counters, c->d_tok, c->d_lz4meta, c->d_lz4meta + n, c->d_dbg);
     if (!(skip & 2) && maybe_lz4)
         hipLaunchKernelGGL(k_lz4_wave, dim3((u32)n), dim3(64), 0, st, src, read_lo, read_hi, desc, dst, res,
-                           ring ? (const u32*)(c->d_lz4meta + n) : (const u32*)(c->d_lists + L_LZ4 * stride), c->d_counters, c->d_dbg,
-                           ring ? (int)C_LZ4_LEFT : (int)L_LZ4);
+                           (const u32*)(c->d_lists + L_LZ4 * stride), c->d_counters, c->d_dbg, (int)L_LZ4);
     ZPK_KEV(ZPK_K_LZ4, 1);
     ZPK_TRACE_STEP("k_lz4_wave");
     // Zstandard in two stages: the FSE sequence streams four per wave into an arena laid out like dst (8 bytes per
@@ -952,24 +828,8 @@ int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8])
     HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[L_NONE]; out[1] = h[L_ZSTD]; out[2] = h[L_LZ4]; out[3] = h[C_ZSTD_TWO_STAGE]; out[4] = h[C_ZSTD_FUSED];
     out[5] = h[ZF_WATCHDOG_WORD]; out[6] = h[ZF_WATCHDOG_WORD + 1]; out[7] = h[13];
-    if (c->fell_back_fused) out[7] |= 0x80000000u;
-    if (c->lz4_general_only) out[7] |= 0x40000000u;         // ... its LZ4 token lists: general LZ4 decoder only          // the batch could not get its sequence arena: fused decoder only
+    if (c->fell_back_fused) out[7] |= 0x80000000u;          // the batch could not get its sequence arena: fused decoder only
     ZPK_DEV(if (getenv("ZPK_TRACE")) fprintf(stderr, "[zpk] fse marked %u, pass-0 failures %u, last failure status/rc %08x\n", h[13], h[14], h[15]);)
-    return ZPK_OK;
-}
-
-int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
-{
-    if (!c || !out) return ZPK_E_INVALID;
-    CodecLock lk(c);
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
-    u32 h[N_COUNTERS];
-    HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
-    memset(out, 0, 16 * sizeof(uint32_t));
-    out[0] = h[C_LZ4_RING]; out[1] = h[C_LZ4_LEFT];
-    for (int i = 0; i < 9; i++) out[2 + i] = h[C_LZ4_WHY + i];
-    out[11] = h[30]; out[12] = h[31]; out[13] = h[C_LZ4_UNITS];
     return ZPK_OK;
 }
 
@@ -978,8 +838,8 @@ int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
 int zpk_codec_debug_fetch(zpk_codec* c, int what, uint64_t offset, void* host, uint64_t bytes)
 {
     if (!c || !host) return ZPK_E_INVALID;
-    const u8* base = what == 0 ? (const u8*)c->d_zarena : what == 3 ? (const u8*)c->d_lz4meta : what == 4 ? (const u8*)c->d_units : what == 5 ? (const u8*)c->d_tok : (const u8*)c->d_zstate;
-    const u64 cap = what == 0 ? c->zarena_cap : what == 3 ? c->lz4meta_cap : what == 4 ? c->units_cap : what == 5 ? c->tok_cap : c->zstate_cap;
+    const u8* base = what == 0 ? (const u8*)c->d_zarena : (const u8*)c->d_zstate;
+    const u64 cap = what == 0 ? c->zarena_cap : c->zstate_cap;
     if (!base || offset > cap || bytes > cap - offset) return ZPK_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
@@ -991,10 +851,8 @@ int zpk_codec_set_option(zpk_codec* c, int option, int value)
 {
     if (!c) return ZPK_E_INVALID;
     CodecLock lk(c);
-    switch (option) {
-    case ZPK_OPT_LZ4_RING: c->opt_lz4_ring = value ? 1 : 0; return ZPK_OK;
-    default: return ZPK_E_INVALID;
-    }
+    (void)option; (void)value;                 // no options at present (round 2's opt-in LZ4 ring path lost to the default and was removed)
+    return ZPK_E_INVALID;
 }
 
 int zpk_codec_set_profiling(zpk_codec* c, int enabled)

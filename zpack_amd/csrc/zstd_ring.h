@@ -1,4 +1,4 @@
-// zstd_ring.h — the Zstandard execute stage through the LDS output ring of lz4_ring.h.
+// zstd_ring.h — the Zstandard execute stage through the LDS output ring of lx_ring.h.
 //
 // What.  k_zstd_fse (zstd_fse4.h) has left an entry's sequences, packed, in the arena; what remains (lib/zpack_read.c:376-411:
 // ZSTD_decompressStream until the frame ends, then the XXH3 of the result, :466) is literals + execution + hash.  The first
@@ -11,7 +11,7 @@
 // Exactness.  Same contract as k_lz4_exec: anything this path does not take (frame checksums, an inconsistency of any
 // kind) leaves the entry to the general decoder k_zstd, whose verdict is the reference's.
 #pragma once
-#include "lz4_ring.h"
+#include "lx_ring.h"
 #include "zstd_wg.h"
 
 namespace zpk {
