@@ -164,6 +164,10 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
 enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2 /* k_lz4_wave */, ZPK_K_ZSTD = 3 /* k_zstd_exec + k_zstd */, ZPK_K_ZSTD_FSE = 4,
        ZPK_K_PACK = 5, ZPK_K_RESERVED6 = 6, ZPK_K_ENCODE = 7, ZPK_K_COUNT = 8 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
+/* out[0], out[1] = LZ4 / Zstandard entries of the most recent decode batch whose first decode ran out of its time budget (a
+ * contended or preempted GPU) and that were decoded again, behind the batch, with a 64 x larger one — a slow wave is not a
+ * verdict; expected 0 on an idle GPU */
+int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16]);
 /* counters of the most recent decode batch (synchronises): out[0..2] = entries on the stored / zstd / lz4 work
  * lists, out[3] = Zstandard entries finished on pre-decoded sequences (two-stage path), out[4] = by the fused decoder,
  * out[5], out[6] = entries / waves the pre-decode kernel gave up on (watchdog; expected 0) */

@@ -359,3 +359,53 @@ def test_lz4_decoder_shapes_vs_oracle(codec, mix, size, n):
         assert rc == 0 and bad.size == 0, (i, "class", int(b.classes[i]), "first bad byte", int(bad[0]) if bad.size else -1, "of", k)
         nxt = int(desc[i + 1]["dst_offset"]) if i + 1 < n else len(out) - 64
         assert (out[a + k:nxt] == 0xA5).all(), ("bytes past the entry were written", i)
+
+
+_RETRY_SCRIPT = r"""
+import json, os, sys
+import numpy as np
+import torch
+import zpack_amd
+from benchdata import datagen as dg
+codec = zpack_amd.Codec(0)
+dev = torch.device("cuda:0")
+out = {}
+for name, method, level in (("lz4", dg.LZ4, 0), ("zstd", dg.ZSTD, 3)):
+    b = dg.Batch(10, 6 << 20, 8 << 20, method=method, level=level, seed=31, mix=dg.TEXT)      # large: the budget is polled every 256 steps
+    desc, total = zpack_amd.decode_descs_from_batch(b)
+    src = torch.from_numpy(b.archive).to(dev)
+    dst = torch.zeros(total, dtype=torch.uint8, device=dev)
+    ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    dres = torch.zeros(b.n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+    codec.decode_batch_device(src, ddesc, b.n, dst, dres)
+    torch.cuda.synchronize()
+    r = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)
+    st = codec.decode_stats()
+    out[name] = dict(all_ok=bool((r["status"] == 0).all()), hashes=bool(np.array_equal(r["hash"], b.hashes)), details=[int(x) for x in set(r["detail"].tolist())],
+                     retried=int(st["retried_" + name]), n=b.n)
+print(json.dumps(out))
+"""
+
+
+def test_watchdog_expiry_is_retried_not_reported():
+    """A wave that runs out of its time budget does not give a verdict (the reference has no notion of `too slow`): the entry is
+    decoded again with a 64 x larger budget behind the batch.  A -DZPK_DEVELOPER build with ZPK_WD_SCALE=0 spends every budget at the
+    first poll: all large entries take the retry path, and every status, hash and detail equals the normal run's."""
+    import subprocess
+    import sys
+    so = os.path.join(os.path.dirname(zpack_amd.CODEC_SO), "dev", "libzpk_codec_dev.so")
+    assert os.path.exists(so), "zpack_amd/dev/libzpk_codec_dev.so is built by zpack_amd.build.build_all()"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for scale in ("0", "1"):
+        # (ZPK_ZSTD_FUSED: the Zstandard entries go straight to the full decoder k_zstd, whose budget the hook scales; on the two-stage
+        # path a stage that runs out of budget hands its entry to k_zstd anyway)
+        env = dict(os.environ, ZPACK_AMD_CODEC_SO=so, ZPK_WD_SCALE=scale, ZPK_ZSTD_FUSED="1", PYTHONPATH=root)
+        p = subprocess.run([sys.executable, "-c", _RETRY_SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=250, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[scale] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    for name in ("lz4", "zstd"):
+        tiny, normal = res["0"][name], res["1"][name]
+        assert normal["all_ok"] and normal["hashes"] and normal["retried"] == 0, normal
+        assert tiny["all_ok"] and tiny["hashes"] and tiny["details"] == [0], tiny           # no 0xDEAD anywhere: same verdicts as the normal run
+        assert tiny["retried"] >= tiny["n"] // 2, tiny                                       # and the retry launches really did the work

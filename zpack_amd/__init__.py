@@ -147,8 +147,11 @@ class Codec:
         """Counters of the last decode batch: entries per method and how the Zstandard ones were finished."""
         a = (C.c_uint32 * 8)()
         self._chk(self.L.zpk_codec_decode_stats(self.h, a), "decode_stats")
+        b = (C.c_uint32 * 16)()
+        self.L.zpk_codec_decode_stats2.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        self._chk(self.L.zpk_codec_decode_stats2(self.h, b), "decode_stats2")
         return dict(stored=a[0], zstd=a[1], lz4=a[2], zstd_two_stage=a[3], zstd_fused=a[4], fse_watchdog=a[5], fse_budget=a[6],
-                    zstd_arena_refused=bool(a[7] >> 31))
+                    zstd_arena_refused=bool(a[7] >> 31), retried_lz4=b[0], retried_zstd=b[1])
 
     def debug_fetch(self, what, offset, count, dtype):
         a = np.zeros(count, dtype=dtype)

@@ -74,6 +74,25 @@ def build_codec(force=False, verbose=False):
     return CODEC_SO
 
 
+def build_codec_dev(force=False, verbose=False):
+    """zpack_amd/dev/libzpk_codec_dev.so: the same kernels with -DZPK_DEVELOPER (environment hooks: ZPK_WD_SCALE, ZPK_TRACE, ZPK_SKIP ...),
+    loaded only by the tests that need a hook (ZPACK_AMD_CODEC_SO); the product library reads no environment in its launch path"""
+    out = os.path.join(HERE, "dev", "libzpk_codec_dev.so")
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "zpack_codec.h")]
+    dig = _stale(out, srcs, "dev")
+    if not force and dig is None:
+        return out
+    dig = dig or _digest(srcs, "dev")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-DZPK_DEVELOPER",
+           "-o", out, os.path.join(CSRC, "zpk_codec.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    _stamp(out, dig)
+    return out
+
+
 def build_zpack(force=False, verbose=False):
     host = os.path.join(HERE, "host")
     csrcs = sorted(os.path.join(host, f) for f in os.listdir(host) if f.endswith(".c"))
@@ -121,6 +140,7 @@ def build_helpers():
 
 def build_all(force=False, verbose=False):
     build_codec(force, verbose)
+    build_codec_dev(force, verbose)
     if os.path.isdir(os.path.join(HERE, "host")):
         build_zpack(force, verbose)
         build_programs(force, verbose)

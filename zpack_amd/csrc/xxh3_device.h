@@ -6,8 +6,8 @@
 // Long inputs (> 240 B): the 8 u64 accumulators are spread over the wave.  Lane l owns the 16-byte
 // slot l of a 1 KiB block = stripe (l >> 2), accumulator pair q = (l & 3).  Within a block the 16
 // stripe contributions to one accumulator only ADD, so they are summed across the 16 lanes that share
-// q with xor-shuffles; the per-block scramble then runs redundantly in every lane.  One block costs
-// one 16 B/lane load (1 KiB per wave instruction, fully coalesced) and ~100 VALU/DPP instructions.
+// q with DPP row rotations + v_permlane16/32_swap (no LDS); the per-block scramble then runs redundantly in every lane.  One block
+// costs one 16 B/lane load (1 KiB per wave instruction, fully coalesced) and ~70 VALU/DPP instructions.
 #pragma once
 #include "zpk_device.h"
 
@@ -138,10 +138,42 @@ struct Xxh3Wave {
         c1 = (u64)(u32)x1 * (u64)(u32)(x1 >> 32) + d0;      // acc[2q+1] += product(2q+1) + data(2q)
     }
 
+    // Sum over the 16 lanes that share q = lane & 3 (lanes q, q + 4, ... q + 60), result in all of them.  No LDS: inside a DPP row
+    // two rotations (row_ror:4, row_ror:8) add up the four lanes q + 4i; across the four rows v_permlane16_swap / v_permlane32_swap
+    // (gfx950) exchange whole rows / halves between a value and its copy, so that value + copy is the sum of the pair.  (Round 2 did
+    // this with 16 ds_bpermute per 1 KiB block: ~100 LDS cycles per block on a CU whose LDS pipe the decoders keep 80 % busy.)
+    template <int CTRL>
+    static __device__ __forceinline__ u64 add_rotated(u64 c)
+    {
+        const u32 rl = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)c, CTRL, 0xf, 0xf, false);
+        const u32 rh = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(c >> 32), CTRL, 0xf, 0xf, false);
+        return c + (((u64)rh << 32) | rl);
+    }
+    static __device__ __forceinline__ u64 add_rows(u64 c)
+    {
+        const u32 lo = (u32)c, hi = (u32)(c >> 32);
+        auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const u64 s = (((u64)h16[0] << 32) | l16[0]) + (((u64)h16[1] << 32) | l16[1]);        // rows {0,1} and {2,3} summed pairwise
+        const u32 slo = (u32)s, shi = (u32)(s >> 32);
+        auto l32 = __builtin_amdgcn_permlane32_swap(slo, slo, false, false);
+        auto h32 = __builtin_amdgcn_permlane32_swap(shi, shi, false, false);
+        return (((u64)h32[0] << 32) | l32[0]) + (((u64)h32[1] << 32) | l32[1]);
+    }
+    // Which form is faster depends on what the kernel around it is short of (measured, round 3): k_lz4_wave is bound by vector
+    // issue with LDS cycles to spare — there the 16 ds_bpermute are the cheaper ones (508 vs 498 GiB/s on text); the Zstandard execute
+    // stage is short of LDS cycles and gains with the DPP / permlane form (13.1 -> 12.7 ms on C3).
+    template <bool NO_LDS>
     static __device__ __forceinline__ void reduce16(u64& c0, u64& c1)
     {
-        #pragma unroll
-        for (int m = 4; m < 64; m <<= 1) { c0 += shfl_xor64(c0, m); c1 += shfl_xor64(c1, m); }
+        if (!NO_LDS) {
+            #pragma unroll
+            for (int m = 4; m < 64; m <<= 1) { c0 += shfl_xor64(c0, m); c1 += shfl_xor64(c1, m); }
+        } else {
+            c0 = add_rotated<0x124>(c0); c1 = add_rotated<0x124>(c1);         // row_ror:4
+            c0 = add_rotated<0x128>(c0); c1 = add_rotated<0x128>(c1);         // row_ror:8
+            c0 = add_rows(c0); c1 = add_rows(c1);
+        }
     }
 
     __device__ __forceinline__ void scramble()
@@ -155,7 +187,7 @@ struct Xxh3Wave {
     {
         u64 c0, c1;
         slot(d.lo, d.hi, k0, k1, c0, c1);
-        reduce16(c0, c1);
+        reduce16<false>(c0, c1);
         a0 += c0; a1 += c1;
         scramble();
     }
@@ -173,7 +205,7 @@ struct Xxh3Wave {
             u128 d = ld128(end - 64 + 16 * q);
             slot(d.lo, d.hi, sec64(121 + 16 * q), sec64(121 + 16 * q + 8), c0, c1);
         }
-        reduce16(c0, c1);
+        reduce16<false>(c0, c1);
         a0 += c0; a1 += c1;
         u64 t = mul128_fold64(a0 ^ sec64(11 + 16 * q), a1 ^ sec64(11 + 16 * q + 8));
         t += shfl_xor64(t, 1);
@@ -202,7 +234,7 @@ struct Xxh3Lite {
         } else { k0 = sec64(8 * s + 16 * q); k1 = sec64(8 * s + 16 * q + 8); s0 = sec64(128 + 16 * q); s1 = sec64(128 + 16 * q + 8); }
         u64 c0, c1;
         Xxh3Wave::slot(d.lo, d.hi, k0, k1, c0, c1);
-        Xxh3Wave::reduce16(c0, c1);
+        Xxh3Wave::reduce16<true>(c0, c1);
         a0 += c0; a1 += c1;
         a0 = ((a0 ^ (a0 >> 47)) ^ s0) * ZPK_P32_1;
         a1 = ((a1 ^ (a1 >> 47)) ^ s1) * ZPK_P32_1;

@@ -36,7 +36,11 @@ using namespace zpk;
 // counters layout (u32): [0..3] count per work list, [4..7] dequeue head per list
 enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4, N_LISTS = 3 };
 // [8] dequeue head of k_zstd_fse, [9] Zstandard entries finished on pre-decoded sequences, [10] finished by the fused decoder
-enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT = 17, N_COUNTERS = 32 };
+enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT = 17,
+       C_RETRY_LZ4 = 18, C_RETRY_ZSTD = 19,     // entries whose decoder ran out of its time budget: decoded again by the retry launches
+       C_RETRY_HEAD = 20,                       // dequeue head of the Zstandard retry launch
+       N_COUNTERS = 32 };
+enum { N_LISTS_ALLOC = N_LISTS + 2 };           // + the two retry lists
 
 // ------------------------------------------------------------------------------------ kernels
 
@@ -157,45 +161,78 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
     }
 }
 
+// one LZ4 entry, one wave.  retry_list != nullptr: a decode that ran out of its time budget is not reported — the entry goes on that
+// list (counters[C_RETRY_LZ4]) and k_lz4_retry decodes it again behind the batch with ZPK_WATCHDOG_RETRY_SCALE times the budget.
+__device__ __forceinline__ void lz4_entry_wave(Lz4WaveShared& shw, const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
+                                               const zpk_decode_desc* __restrict__ desc, u8* dst, zpk_decode_result* __restrict__ res,
+                                               u32 e, u32* __restrict__ counters, u64* __restrict__ dbg, u32* __restrict__ retry_list,
+                                               u32 wd_scale, int lane)
+{
+    const zpk_decode_desc d = desc[e];
+    const u8* in = uni_ptr(src + d.src_offset);
+    u8* out = uni_ptr(dst + d.dst_offset);
+    Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity), wd_scale);
+    SeqStats stt = {};
+    const u64 t_all = SEQ_T(); (void)t_all;
+    DecodeOut o = lz4f_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
+#ifdef ZPK_STATS
+    if (dbg && lane == 0) {
+        u64* g = dbg + (u64)e * 8;
+        g[0] = stt.t_parse; g[1] = stt.t_lit; g[2] = stt.t_dep; g[3] = stt.t_rounds;
+        g[4] = ((u64)stt.batches << 32) | stt.rounds; g[5] = ((u64)stt.coops << 32) | stt.asm_batches; g[6] = SEQ_T() - t_all;
+        g[7] = ((u64)stt.fix_iters << 32) | stt.chunks;
+#ifdef ZPK_STATS_PARSE
+        g[0] = stt.t_stage; g[1] = stt.t_walk1; g[2] = stt.t_fix; g[3] = stt.t_emit; g[4] = stt.t_tok;
+        g[5] = ((u64)stt.hops_first << 32) | stt.hops_fix; g[6] = stt.slow_hops;
+#endif
+    }
+#else
+    (void)dbg; (void)t_all;
+#endif
+    if (wd.fired && retry_list) {                               // slow is not a verdict: again, later, with the large budget
+        lane0_guard();
+        if (lane == 0) retry_list[atomicAdd(&counters[C_RETRY_LZ4], 1u)] = e;
+        return;
+    }
+    // lib/zpack_read.c:421-450
+    int status = R_OK;
+    if (o.rc == D_MALFORMED) status = R_DECOMPRESS_FAILED;
+    else if (o.rc == D_TRUNCATED) status = o.produced < d.dst_capacity ? R_FILE_INCOMPLETE : R_BUFFER_TOO_SMALL;
+    else if (o.rc == D_DST_FULL) status = R_BUFFER_TOO_SMALL;
+    finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
+}
+
+// one wave per slot of the LZ4 work list: the hardware dispatcher is the load balancer
 __global__ __launch_bounds__(64, 8) void k_lz4_wave(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
-                                                  const u32* __restrict__ counters, u64* __restrict__ dbg, int count_word)
+                                                  u32* __restrict__ counters, u64* __restrict__ dbg, u32* __restrict__ retry_list
+#ifdef ZPK_DEVELOPER
+                                                  , u32 wd_scale
+#endif
+                                                  )
 {
-    // `list` / counters[count_word]: the LZ4 work list
+#ifndef ZPK_DEVELOPER
+    const u32 wd_scale = 1u;
+#endif
     const int lane = lane_id();
     __shared__ Lz4WaveShared shw;
     u32 idx;
-    if (my_slot(counters, count_word, idx)) {
-        const u32 e = uni(list[idx]);
-        const zpk_decode_desc d = desc[e];
-        const u8* in = uni_ptr(src + d.src_offset);
-        u8* out = uni_ptr(dst + d.dst_offset);
-        Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
-        SeqStats stt = {};
-        const u64 t_all = SEQ_T(); (void)t_all;
-        DecodeOut o = lz4f_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
-#ifdef ZPK_STATS
-        if (dbg && lane == 0) {
-            u64* g = dbg + (u64)e * 8;
-            g[0] = stt.t_parse; g[1] = stt.t_lit; g[2] = stt.t_dep; g[3] = stt.t_rounds;
-            g[4] = ((u64)stt.batches << 32) | stt.rounds; g[5] = ((u64)stt.coops << 32) | stt.asm_batches; g[6] = SEQ_T() - t_all;
-            g[7] = ((u64)stt.fix_iters << 32) | stt.chunks;
-#ifdef ZPK_STATS_PARSE
-            g[0] = stt.t_stage; g[1] = stt.t_walk1; g[2] = stt.t_fix; g[3] = stt.t_emit; g[4] = stt.t_tok;
-            g[5] = ((u64)stt.hops_first << 32) | stt.hops_fix; g[6] = stt.slow_hops;
-#endif
-        }
-#else
-        (void)dbg; (void)t_all;
-#endif
-        // lib/zpack_read.c:421-450
-        int status = R_OK;
-        if (o.rc == D_MALFORMED) status = R_DECOMPRESS_FAILED;
-        else if (o.rc == D_TRUNCATED) status = o.produced < d.dst_capacity ? R_FILE_INCOMPLETE : R_BUFFER_TOO_SMALL;
-        else if (o.rc == D_DST_FULL) status = R_BUFFER_TOO_SMALL;
-        finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
-    }
+    if (my_slot(counters, L_LZ4, idx))
+        lz4_entry_wave(shw, src, read_lo, read_hi, desc, dst, res, uni(list[idx]), counters, dbg, retry_list, wd_scale, lane);
+}
+
+// the entries k_lz4_wave gave up on (normally none): a small grid, ZPK_WATCHDOG_RETRY_SCALE times the budget, and now the verdict counts
+__global__ __launch_bounds__(64, 8) void k_lz4_retry(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
+                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
+                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
+                                                   u32* __restrict__ counters, u64* __restrict__ dbg)
+{
+    const int lane = lane_id();
+    __shared__ Lz4WaveShared shw;
+    const u32 n_slots = uni(counters[C_RETRY_LZ4]);
+    for (u32 idx = uni((u32)blockIdx.x); idx < n_slots; idx += gridDim.x)
+        lz4_entry_wave(shw, src, read_lo, read_hi, desc, dst, res, uni(list[idx]), counters, dbg, nullptr, (u32)ZPK_WATCHDOG_RETRY_SCALE, lane);
 }
 
 // Stage 2 of the two-stage Zstandard path: entries whose sequences k_zstd_fse left in the arena (zstate == 1) are run
@@ -313,9 +350,11 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, ZSTD_EXEC_WAVES) void k_zstd_exec(
 __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                           u8* dst, zpk_decode_result* __restrict__ res,
                                                           const u32* __restrict__ list, u32* __restrict__ counters,
-                                                          u8* __restrict__ lit_scratch, u64* __restrict__ dbg, int count_word)
+                                                          u8* __restrict__ lit_scratch, u64* __restrict__ dbg, int count_word,
+                                                          int head_word, u32* __restrict__ retry_list, int retry_word, u32 wd_scale)
 {
-    // `list` / counters[count_word]: the Zstandard work list itself, or what k_zstd_exec left over
+    // `list` / counters[count_word]: the Zstandard work list itself, what k_zstd_exec left over, or (retry_list == nullptr) the
+    // entries the first launch gave up on; counters[head_word]: the dequeue head of this launch
     const int lane = lane_id();
     const u32 nz = uni(counters[count_word]);
     if (nz == 0) return;
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restric
     for (;;) {
         lane0_guard();
         u32 v = 0;
-        if (lane == 0) v = atomicAdd(&counters[L_COUNT + L_ZSTD], 1u);
+        if (lane == 0) v = atomicAdd(&counters[head_word], 1u);
         const u32 idx = uni(v);
         lane0_guard();
         if (idx >= nz) break;
@@ -334,7 +373,7 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restric
         const zpk_decode_desc d = desc[e];
         const u8* in = uni_ptr(src + d.src_offset);
         u8* out = uni_ptr(dst + d.dst_offset);
-        Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
+        Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity), wd_scale);
 #ifdef ZPK_STATS
         ZstdStats zs = {};
         const u64 t_all = SEQ_T();
@@ -348,6 +387,12 @@ __global__ __launch_bounds__(ZSTD_WG_THREADS, 3) void k_zstd(const u8* __restric
         DecodeOut o = zstd_decode_wave<false>(sh, wd, in, uni64(d.comp_size), out, uni64(d.dst_capacity), lit, lane);
 #endif
         int status = o.rc == D_OK ? R_OK : R_DECOMPRESS_FAILED;               // lib/zpack_read.c:384-388
+        if (wd.fired && retry_list) {                               // slow is not a verdict: again, later, with the large budget
+            lane0_guard();
+            if (lane == 0) retry_list[atomicAdd(&counters[retry_word], 1u)] = e;
+            lane0_guard();
+            continue;
+        }
         finish_entry(d, res, e, status, wd.fired ? 0xDEADu : (u32)(-o.rc), o.produced, out, lane);
         lane0_guard();
         if (lane == 0) atomicAdd(&counters[C_ZSTD_FUSED], 1u);
@@ -507,8 +552,10 @@ int zpk_codec_device(const zpk_codec* c) { return c ? c->device : -1; }
 // the product launch path reads no environment and can neither drop a kernel nor end the host process.
 #ifdef ZPK_DEVELOPER
 #define ZPK_DEV(x) x
+#define ZPK_WD_ARG , wd_scale
 #else
 #define ZPK_DEV(x)
+#define ZPK_WD_ARG
 #endif
 
 static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* read_lo, const u8* read_hi,
@@ -517,8 +564,12 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     if (n == 0) return ZPK_OK;
     if (n > 0x7FFFFFF0ull) return ZPK_E_INVALID;               // one workgroup per LZ4 entry: the grid's x limit
     int rc;
-    if ((rc = grow(c, (void**)&c->d_lists, &c->list_cap, N_LISTS * n * sizeof(u32)))) return rc;
-    const u64 stride = c->list_cap / (N_LISTS * sizeof(u32));
+    if ((rc = grow(c, (void**)&c->d_lists, &c->list_cap, N_LISTS_ALLOC * n * sizeof(u32)))) return rc;
+    const u64 stride = c->list_cap / (N_LISTS_ALLOC * sizeof(u32));
+    u32* const retry_lz4 = c->d_lists + (u64)N_LISTS * stride;
+    u32* const retry_zstd = c->d_lists + (u64)(N_LISTS + 1) * stride;
+    u32 wd_scale = 1; (void)wd_scale;
+    ZPK_DEV(static const int wd_env = getenv("ZPK_WD_SCALE") ? atoi(getenv("ZPK_WD_SCALE")) : 1; wd_scale = (u32)wd_env;)
     int skip = 0; (void)skip;
 #ifdef ZPK_DEVELOPER
     static const int want_dbg = getenv("ZPK_DEBUG_TIMING") ? atoi(getenv("ZPK_DEBUG_TIMING")) : 0;
@@ -553,7 +604,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_KEV(ZPK_K_LZ4, 0);
     if (!(skip & 2) && maybe_lz4)
         hipLaunchKernelGGL(k_lz4_wave, dim3((u32)n), dim3(64), 0, st, src, read_lo, read_hi, desc, dst, res,
-                           (const u32*)(c->d_lists + L_LZ4 * stride), c->d_counters, c->d_dbg, (int)L_LZ4);
+                           (const u32*)(c->d_lists + L_LZ4 * stride), c->d_counters, c->d_dbg, retry_lz4 ZPK_WD_ARG);
     ZPK_KEV(ZPK_K_LZ4, 1);
     ZPK_TRACE_STEP("k_lz4_wave");
     // Zstandard in two stages: the FSE sequence streams four per wave into an arena laid out like dst (8 bytes per
@@ -586,9 +637,20 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     if (!(skip & 4) && maybe_zstd)
         hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
                        two_stage ? (const u32*)leftover : (const u32*)(c->d_lists + L_ZSTD * stride), c->d_counters, c->d_lit, c->d_dbg,
-                       two_stage ? (int)C_LEFT_COUNT : (int)L_ZSTD);
+                       two_stage ? (int)C_LEFT_COUNT : (int)L_ZSTD, (int)(L_COUNT + L_ZSTD), retry_zstd, (int)C_RETRY_ZSTD, wd_scale);
     ZPK_KEV(ZPK_K_ZSTD, 1);
     ZPK_TRACE_STEP("k_zstd");
+    // Entries whose decoder ran out of its time budget (a preempted or contended GPU, not the entry's fault) are decoded again
+    // here, behind everything else of the batch, with ZPK_WATCHDOG_RETRY_SCALE times the budget: small grids that leave at once
+    // when their list is empty (the normal case).
+    if (!(skip & 2) && maybe_lz4)
+        hipLaunchKernelGGL(k_lz4_retry, dim3((u32)(n < 256 ? n : 256)), dim3(64), 0, st, src, read_lo, read_hi, desc, dst, res,
+                           (const u32*)retry_lz4, c->d_counters, c->d_dbg);
+    if (!(skip & 4) && maybe_zstd)
+        hipLaunchKernelGGL(k_zstd, dim3(zstd_grid < 128 ? zstd_grid : 128), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
+                           (const u32*)retry_zstd, c->d_counters, c->d_lit, c->d_dbg, (int)C_RETRY_ZSTD, (int)C_RETRY_HEAD,
+                           (u32*)nullptr, 0, (u32)ZPK_WATCHDOG_RETRY_SCALE);
+    ZPK_TRACE_STEP("retry");
     HIPCHK(c, hipGetLastError());
     return ZPK_OK;
 }
@@ -830,6 +892,21 @@ int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8])
     out[5] = h[ZF_WATCHDOG_WORD]; out[6] = h[ZF_WATCHDOG_WORD + 1]; out[7] = h[13];
     if (c->fell_back_fused) out[7] |= 0x80000000u;          // the batch could not get its sequence arena: fused decoder only
     ZPK_DEV(if (getenv("ZPK_TRACE")) fprintf(stderr, "[zpk] fse marked %u, pass-0 failures %u, last failure status/rc %08x\n", h[13], h[14], h[15]);)
+    return ZPK_OK;
+}
+
+// out[0], out[1] = LZ4 / Zstandard entries of the most recent decode batch whose first decode ran out of its time budget and that
+// were decoded again by the retry launches (expected 0 on an idle GPU)
+int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
+{
+    if (!c || !out) return ZPK_E_INVALID;
+    CodecLock lk(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    u32 h[N_COUNTERS];
+    HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    memset(out, 0, 16 * sizeof(uint32_t));
+    out[0] = h[C_RETRY_LZ4]; out[1] = h[C_RETRY_ZSTD];
     return ZPK_OK;
 }
 

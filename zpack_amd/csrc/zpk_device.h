@@ -165,9 +165,19 @@ __device__ __forceinline__ u64 watchdog_budget(u64 bytes)
     const u64 cap = ~0ull / (4 * ZPK_WATCHDOG_TICKS_PER_BYTE);                       // sizes are untrusted: no wrap
     return (u64)ZPK_WATCHDOG_SECONDS * 100000000ull + (bytes < cap ? bytes : cap) * ZPK_WATCHDOG_TICKS_PER_BYTE;
 }
+// A budget that runs out is NOT a verdict (round 3): the entry goes on a retry list and is decoded again, after the batch's
+// kernels have drained, with ZPK_WATCHDOG_RETRY_SCALE times the budget — a floor of ~30 KB/s per wave, minutes for a 64 KiB
+// entry: only a decoder that really does not terminate reports DECOMPRESS_FAILED / 0xDEAD.  scale 0 (developer builds,
+// ZPK_WD_SCALE=0): the budget is spent at the first poll, every entry that polls takes the retry path.
+#ifndef ZPK_WATCHDOG_RETRY_SCALE
+#define ZPK_WATCHDOG_RETRY_SCALE 64u
+#endif
 struct Watchdog {
     u64 deadline; u32 tick; bool fired;
-    __device__ __forceinline__ void arm(u64 bytes) { deadline = __builtin_amdgcn_s_memrealtime() + watchdog_budget(bytes); tick = 0; fired = false; }
+    __device__ __forceinline__ void arm(u64 bytes, u32 scale = 1u)
+    {
+        deadline = __builtin_amdgcn_s_memrealtime() + watchdog_budget(bytes) * (u64)scale; tick = 0; fired = false;
+    }
     __device__ __forceinline__ bool expired()
     {
         if (((++tick) & 255u) == 0 && __builtin_amdgcn_s_memrealtime() > deadline) fired = true;
