@@ -409,3 +409,28 @@ def test_watchdog_expiry_is_retried_not_reported():
         assert normal["all_ok"] and normal["hashes"] and normal["retried"] == 0, normal
         assert tiny["all_ok"] and tiny["hashes"] and tiny["details"] == [0], tiny           # no 0xDEAD anywhere: same verdicts as the normal run
         assert tiny["retried"] >= tiny["n"] // 2, tiny                                       # and the retry launches really did the work
+
+
+@pytest.mark.parametrize("method,level,n,lo,hi", [(dg.LZ4, 0, 13000, 14000, 30000), (dg.ZSTD, 3, 37500, 5000, 11000), (dg.COIN, 3, 37500, 4000, 12000)])
+def test_host_batch_takes_the_upload_decode_download_pipeline(codec, method, level, n, lo, hi):
+    """zpk_codec_decode_batch_host on a batch large enough for the three-stage pipeline (pieces uploaded by one thread, decoded as they
+    arrive, the output streamed back through the pinned buffers): every status, size and hash, every returned byte (by its XXH3), a
+    byte-level comparison with the oracle on a sample, and entries with a wrong expected hash keep their bytes (lib/zpack_read.c:466-468)."""
+    o = oracle()
+    b = dg.Batch(n, lo, hi, method=method, level=level, seed=41, mix=-1)
+    d = np.zeros(n, dtype=zpack_amd.DECODE_DESC)
+    d["src_offset"] = b.offsets; d["comp_size"] = b.comp_sizes; d["uncomp_size"] = b.uncomp_sizes
+    d["expect_hash"] = b.hashes; d["dst_capacity"] = b.uncomp_sizes; d["method"] = b.methods
+    bad = np.arange(7, n, 997)
+    d["expect_hash"][bad] ^= np.uint64(1)
+    res, outs = codec.decode_batch_host(b.archive, d)
+    want_status = np.zeros(n, dtype=np.int32); want_status[bad] = 15
+    assert np.array_equal(res["status"], want_status), np.nonzero(res["status"] != want_status)[0][:10]
+    assert np.array_equal(res["produced"], b.uncomp_sizes) and np.array_equal(res["hash"], b.hashes)
+    for i in range(n):
+        assert dg.xxh3(outs[i]) == int(b.hashes[i]), i
+    arc = b.archive.tobytes()
+    for i in list(range(0, n, 1501)) + [n - 1]:
+        k = int(b.uncomp_sizes[i])
+        rc, want, _, _ = o.entry_decode(arc, int(b.offsets[i]), int(b.comp_sizes[i]), k, int(b.hashes[i]), int(b.methods[i]), k)
+        assert rc == 0 and outs[i][:k].tobytes() == want
