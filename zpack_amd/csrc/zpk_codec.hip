@@ -550,6 +550,12 @@ void zpk_codec_reset(zpk_codec* c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipGetLastError();
     c->err[0] = 0;
+    // a context keeps its grown staging between batches (the next batch of that size starts at once); a reset gives the large pieces
+    // back — a process that holds many readers can bound what each one retains (zpack_reset_reader_dctx / zpack_reset_writer_cctx)
+    const u64 keep = 64ull << 20;
+    void** bufs[] = { (void**)&c->d_src, (void**)&c->d_dst, (void**)&c->d_zarena, (void**)&c->d_lit };
+    u64* caps[] = { &c->src_cap, &c->dst_cap, &c->zarena_cap, &c->lit_cap };
+    for (int i = 0; i < 4; i++) if (*bufs[i] && *caps[i] > keep) { (void)hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
 }
 const char* zpk_codec_last_error(const zpk_codec* c) { return c ? c->err : "no codec"; }
 int zpk_codec_device(const zpk_codec* c) { return c ? c->device : -1; }

@@ -97,11 +97,13 @@ int main(int argc, char** argv)
         /* one device batch: consecutive entries up to ZPK_BATCH_BYTES of output (an entry larger than that goes alone) */
         zpack_u64 cnt = 0, bytes = 0;
         while (first + cnt < n) {
-            const zpack_u64 u = reader.file_entries[first + cnt].uncomp_size;
-            if (cnt && bytes + u > ZPK_BATCH_BYTES) break;
+            const zpack_u64 u = reader.file_entries[first + cnt].uncomp_size;          /* untrusted: no wrap of the sum, no malloc beyond size_t */
+            if (cnt && (u > ZPK_BATCH_BYTES || bytes + u > ZPK_BATCH_BYTES)) break;
+            if (u > (zpack_u64)(SIZE_MAX / 2)) { printf("Error: \"%s\" claims %" PRIu64 " bytes\n", reader.file_entries[first + cnt].filename, u); rc = 1; break; }
             ptrs[cnt] = reader.file_entries + first + cnt;
             bytes += u; cnt++;
         }
+        if (rc) break;
         if (bytes > buf_cap) {
             free(buf);
             buf = (zpack_u8*)malloc((size_t)bytes);
@@ -127,19 +129,22 @@ int main(int argc, char** argv)
             const size_t ol = outdir ? strlen(outdir) : 0, fl = strlen(e->filename);
             char* path = (char*)malloc(ol + fl + 3);
             char* name = (char*)malloc(fl + 1);
+            if (!path || !name) { printf("Error: out of memory\n"); free(path); free(name); errors++; continue; }
             if (junk) strcpy(name, base_name(e->filename)); else safe_path(e->filename, name);
             if (outdir) { memcpy(path, outdir, ol); path[ol] = '/'; strcpy(path + ol + 1, name); } else strcpy(path, name);
             FILE* fp = NULL;
-            if (!*name || !mkdir_p_for(path)) printf("Error: Failed to create output directory for \"%s\" %s\n", path, strerror(errno));
-            else if (!(fp = fopen(path, "wb"))) printf("Failed to open \"%s\" for writing\n", path);
-            else if (e->uncomp_size && fwrite(buf + offs[k], 1, (size_t)e->uncomp_size, fp) != e->uncomp_size) printf("Error: Failed to write data to \"%s\"", path);
-            if (fp) fclose(fp); else errors++;
+            int failed = 0;
+            if (!*name || !mkdir_p_for(path)) { printf("Error: Failed to create output directory for \"%s\" %s\n", path, strerror(errno)); failed = 1; }
+            else if (!(fp = fopen(path, "wb"))) { printf("Failed to open \"%s\" for writing\n", path); failed = 1; }
+            else if (e->uncomp_size && fwrite(buf + offs[k], 1, (size_t)e->uncomp_size, fp) != e->uncomp_size) { printf("Error: Failed to write data to \"%s\"\n", path); failed = 1; }
+            if (fp && fclose(fp) != 0 && !failed) { printf("Error: Failed to write data to \"%s\"\n", path); failed = 1; }
+            errors += failed;
             free(path); free(name);
         }
         first += cnt;
     }
     if (rc == 0) {
-        if (extract) { if (errors) printf("-- Errors: %d\n", errors); printf("-- Done.\n"); }
+        if (extract) { if (errors) { printf("-- Errors: %d\n", errors); rc = 1; } printf("-- Done.\n"); }
         else printf("-- Done.\n-- Corrupted files: %" PRIu64 "/%" PRIu64 "\n", corrupt, n);
     }
     free(buf); free(ptrs); free(offs); free(results);
