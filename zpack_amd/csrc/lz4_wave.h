@@ -50,6 +50,10 @@ struct ByteWindow {
 
 struct DecodeOut { int rc; u64 produced; };
 
+// Streaming (zpk_stream.inc): a frame decode that runs out of INPUT at a block boundary can be picked up again when more bytes have
+// arrived.  LZ4 keeps no state between blocks but the positions (the frame header is parsed again, it is a few bytes).
+struct Lz4Resume { u64 ip_off, op_off; u32 in_blocks; };
+
 // ---- LZ4 block decode: lane-parallel parse out of a per-wave LDS chunk, batched execution ----------
 //
 // The token chain is serial, and walking it wave-uniformly costs ~1000 cycles per sequence (a long
@@ -378,7 +382,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
 
 // whole frame.  src_lo/src_hi bound what may be READ (the archive image); all values uniform.
 __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* src, u64 src_size, const u8* src_lo, const u8* src_hi,
-                                             u8* dst, u64 dst_cap, int lane)
+                                             u8* dst, u64 dst_cap, int lane, Lz4Resume* rs = nullptr)
 {
     DecodeOut r; r.rc = D_OK; r.produced = 0;
     const u8* ip = src;
@@ -419,8 +423,10 @@ __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, Se
     ip += hdr;
 
     u8* frame_out = op;
+    if (rs && rs->in_blocks) { ip = src + rs->ip_off; op = dst + rs->op_off; }     // resume at the block the last call stopped in front of
     for (;;) {
         if (wd.expired()) { r.rc = D_MALFORMED; return r; }
+        if (rs) { rs->in_blocks = 1; rs->ip_off = (u64)(ip - src); rs->op_off = (u64)(op - dst); }     // everything before this block is done
         if (iend - ip < 4) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
         const u32 bh = uld32(ip);
         ip += 4;
@@ -429,7 +435,7 @@ __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, Se
         const u64 bsz = bh & 0x7FFFFFFFu;
         if (bsz > bmax) { r.rc = D_MALFORMED; return r; }
         if ((u64)(iend - ip) < bsz + (bck ? 4u : 0u)) {
-            if (raw) {      // what is there of a stored block still streams out before the input starves
+            if (raw && !rs) {      // what is there of a stored block still streams out before the input starves
                 u64 n = (u64)(iend - ip); if (n > bsz) n = bsz;
                 bool full = n > (u64)(oend - op);
                 if (full) n = (u64)(oend - op);

@@ -1184,76 +1184,131 @@ __device__ inline void zstd_build_defaults(ZstdShared& sh, int lane)
     __syncthreads();
 }
 
+// Streaming (zpk_stream.inc): a decode that runs out of INPUT in front of a block (or a frame header, or a frame's checksum) leaves
+// everything the next block depends on in a ZstdResume record in memory — positions, frame header fields, repeat offsets, and the
+// whole LDS image (Huffman table for treeless literals, the three sequence tables for Repeat_Mode, the predefined tables) — and is
+// picked up there when more bytes have arrived.  `final`: all of the entry's bytes are present, so a shortage is a malformed frame
+// (the one-shot verdict, lib/zpack_read.c:380-388), not a reason to wait.
+struct alignas(16) ZstdResume {
+    u64 ip_off, op_off, frame_lo_off, fcs, pre_idx;
+    u64 rep0, rep1, rep2;
+    u32 phase;                   // 0 = in front of a frame, 1 = in front of a block, 2 = in front of the frame's checksum
+    u32 fn, cksum, seq_tables_valid;
+    i32 al_ll, al_of, al_ml, pad_;
+    u8  lds[(sizeof(ZstdShared) + 15) & ~15u];
+};
+
+__device__ inline void zstd_lds_image(ZstdShared& sh, u8* image, bool save, int lane)
+{
+    __syncthreads();
+    const u32 n16 = (u32)(sizeof(ZstdShared) / 16);
+    lds_p8 L = to_lds_rw((u8*)&sh);
+    for (u32 i = (u32)lane; i < n16; i += WAVE) {
+        if (save) st128(image + 16 * i, lds_ld128((lds_cp8)(L + 16 * i)));
+        else lds_st128(L + 16 * i, ld128(image + 16 * i));
+    }
+    __syncthreads();
+}
+
 template <bool EXEC_ONLY = false>
 __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const u8* src, u64 src_size, u8* dst, u64 dst_cap, u8* lit_buf, int lane,
-                                             ZstdStats* zs = nullptr, const u64* pre = nullptr)
+                                             ZstdStats* zs = nullptr, const u64* pre = nullptr, ZstdResume* rs = nullptr, bool final = true)
 {
     u64 pre_idx = 0;
     DecodeOut r; r.rc = D_OK; r.produced = 0;
     const u8* ip = src; const u8* iend = src + src_size;
     u8* op = dst; u8* oend = dst + dst_cap;
-    if constexpr (!EXEC_ONLY) if (!sh.defaults_built) { zstd_build_defaults(sh, lane); sh.defaults_built = 1; }
+    bool resuming = rs && uni(rs->phase) != 0;
+    if constexpr (!EXEC_ONLY) if (!resuming && !sh.defaults_built) { zstd_build_defaults(sh, lane); sh.defaults_built = 1; }
     __syncthreads();
-
-    while (ip < iend) {
-        if (wd.expired()) { r.rc = D_MALFORMED; break; }
-        if (iend - ip < 4) { r.rc = D_MALFORMED; break; }
-        const u32 magic = uld32(ip);
-        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
-            if (iend - ip < 8) { r.rc = D_MALFORMED; break; }
-            u64 sz = uld32(ip + 4);
-            if ((u64)(iend - ip) - 8 < sz) { r.rc = D_MALFORMED; break; }
-            ip += 8 + sz;
-            continue;
-        }
-        if (magic != 0xFD2FB528u) { r.rc = D_MALFORMED; break; }
-        // ---- frame header ----
-        if (iend - ip < 6) { r.rc = D_MALFORMED; break; }
-        ip += 4;
-        const u32 fhd = uld8(ip++);
-        const u32 fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, cksum = (fhd >> 2) & 1, did_flag = fhd & 3;
-        if (fhd & 0x08) { r.rc = D_MALFORMED; break; }
-        if (!single) {
-            if (iend - ip < 1) { r.rc = D_MALFORMED; break; }
-            const u32 wdesc = uld8(ip++);
-            if (10 + (wdesc >> 3) > 31) { r.rc = D_MALFORMED; break; }
-        }
-        const u32 dn = did_flag == 3 ? 4 : did_flag;
-        if ((u64)(iend - ip) < dn) { r.rc = D_MALFORMED; break; }
-        u32 dict_id = 0;
-        for (u32 i = 0; i < dn; i++) dict_id |= uld8(ip + i) << (8 * i);
-        ip += dn;
-        if (dict_id != 0) { r.rc = D_MALFORMED; break; }
-        const u32 fn = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
-        if ((u64)(iend - ip) < fn) { r.rc = D_MALFORMED; break; }
-        u64 fcs = 0;
-        for (u32 i = 0; i < fn; i++) fcs |= (u64)uld8(ip + i) << (8 * i);
-        if (fn == 2) fcs += 256;
-        ip += fn;
-
-        ZFrameState fs;
-        fs.wd = &wd; fs.zs = zs;
-        fs.rep0 = 1; fs.rep1 = 4; fs.rep2 = 8; fs.seq_tables_valid = false; fs.al_ll = fs.al_of = fs.al_ml = 0;
-        fs.pre = pre; fs.pre_idx = pre_idx;
+    if (rs && !resuming && uni(rs->ip_off | rs->op_off) != 0) { ip = src + uni64(rs->ip_off); op = dst + uni64(rs->op_off); }    // in front of a later frame
+    // a shortage of input: wait (streaming, more to come) or malformed (everything is here)
+    const int SHORT = rs && !final ? D_TRUNCATED : D_MALFORMED;
+    ZFrameState fs;
+    fs.wd = &wd; fs.zs = zs;
+    u32 fn = 0, cksum = 0; u64 fcs = 0; u8* frame_lo = op;
+    // what a resumed call needs: written (lane 0) whenever the decode stops short of input
+    auto park = [&](u32 phase, const u8* at) {
+        if (!rs) return;
+        if (phase != 0) zstd_lds_image(sh, rs->lds, true, lane);
         lane0_guard();
-        if (lane == 0) sh.huf_valid = 0;
-        __syncthreads();
-        u8* frame_lo = op;
+        if (lane == 0) {
+            rs->phase = phase; rs->ip_off = (u64)(at - src); rs->op_off = (u64)(op - dst); rs->frame_lo_off = (u64)(frame_lo - dst);
+            rs->fcs = fcs; rs->fn = fn; rs->cksum = cksum; rs->pre_idx = fs.pre_idx;
+            rs->rep0 = fs.rep0; rs->rep1 = fs.rep1; rs->rep2 = fs.rep2; rs->seq_tables_valid = fs.seq_tables_valid ? 1u : 0u;
+            rs->al_ll = fs.al_ll; rs->al_of = fs.al_of; rs->al_ml = fs.al_ml;
+        }
+    };
+
+    while (ip < iend || resuming) {
+        if (wd.expired()) { r.rc = D_MALFORMED; break; }
+        u32 phase = 1;
+        if (resuming) {
+            resuming = false;
+            phase = uni(rs->phase);
+            ip = src + uni64(rs->ip_off); op = dst + uni64(rs->op_off); frame_lo = dst + uni64(rs->frame_lo_off);
+            fcs = uni64(rs->fcs); fn = uni(rs->fn); cksum = uni(rs->cksum);
+            fs.rep0 = uni64(rs->rep0); fs.rep1 = uni64(rs->rep1); fs.rep2 = uni64(rs->rep2); fs.seq_tables_valid = uni(rs->seq_tables_valid) != 0;
+            fs.al_ll = (int)uni((u32)rs->al_ll); fs.al_of = (int)uni((u32)rs->al_of); fs.al_ml = (int)uni((u32)rs->al_ml);
+            fs.pre = pre; fs.pre_idx = uni64(rs->pre_idx);
+            zstd_lds_image(sh, rs->lds, false, lane);
+        } else {
+            const u8* const frame_at = ip;
+            frame_lo = op; fn = 0; cksum = 0; fcs = 0;
+            fs.rep0 = 1; fs.rep1 = 4; fs.rep2 = 8; fs.seq_tables_valid = false; fs.al_ll = fs.al_of = fs.al_ml = 0; fs.pre = pre; fs.pre_idx = pre_idx;
+            if (iend - ip < 4) { r.rc = SHORT; park(0, frame_at); break; }
+            const u32 magic = uld32(ip);
+            if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+                if (iend - ip < 8) { r.rc = SHORT; park(0, frame_at); break; }
+                u64 sz = uld32(ip + 4);
+                if ((u64)(iend - ip) - 8 < sz) { r.rc = SHORT; park(0, frame_at); break; }
+                ip += 8 + sz;
+                continue;
+            }
+            if (magic != 0xFD2FB528u) { r.rc = D_MALFORMED; break; }
+            // ---- frame header ----
+            if (iend - ip < 6) { r.rc = SHORT; park(0, frame_at); break; }
+            ip += 4;
+            const u32 fhd = uld8(ip++);
+            const u32 fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+            cksum = (fhd >> 2) & 1;
+            if (fhd & 0x08) { r.rc = D_MALFORMED; break; }
+            if (!single) {
+                if (iend - ip < 1) { r.rc = SHORT; park(0, frame_at); break; }
+                const u32 wdesc = uld8(ip++);
+                if (10 + (wdesc >> 3) > 31) { r.rc = D_MALFORMED; break; }
+            }
+            const u32 dn = did_flag == 3 ? 4 : did_flag;
+            if ((u64)(iend - ip) < dn) { r.rc = SHORT; park(0, frame_at); break; }
+            u32 dict_id = 0;
+            for (u32 i = 0; i < dn; i++) dict_id |= uld8(ip + i) << (8 * i);
+            ip += dn;
+            if (dict_id != 0) { r.rc = D_MALFORMED; break; }
+            fn = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+            if ((u64)(iend - ip) < fn) { r.rc = SHORT; park(0, frame_at); break; }
+            for (u32 i = 0; i < fn; i++) fcs |= (u64)uld8(ip + i) << (8 * i);
+            if (fn == 2) fcs += 256;
+            ip += fn;
+            lane0_guard();
+            if (lane == 0) sh.huf_valid = 0;
+            __syncthreads();
+        }
         bool fail = false;
-        for (;;) {
+        while (phase == 1) {
             if (wd.expired()) { r.rc = D_MALFORMED; fail = true; break; }
-            if (iend - ip < 3) { r.rc = D_MALFORMED; fail = true; break; }
+            const u8* const block_at = ip;
+            if (iend - ip < 3) { r.rc = SHORT; park(1, block_at); fail = true; break; }
             const u32 bh = uld8(ip) | (uld8(ip + 1) << 8) | (uld8(ip + 2) << 16);
             ip += 3;
             const bool last = bh & 1; const u32 type = (bh >> 1) & 3; const u64 bsize = bh >> 3;
             if (type == 3) { r.rc = D_MALFORMED; fail = true; break; }
             if (type == 0) {
-                if (bsize > (u64)(iend - ip)) { r.rc = D_MALFORMED; fail = true; break; }
+                if (bsize > (u64)(iend - ip)) { r.rc = SHORT; park(1, block_at); fail = true; break; }
                 if (bsize > (u64)(oend - op)) { r.rc = D_DST_FULL; fail = true; break; }
                 for (u64 i = (u64)lane * 16; i < bsize; i += WAVE * 16) gcopy_upto16(op + i, ip + i, (u32)(bsize - i < 16 ? bsize - i : 16));
                 ip += bsize; op += bsize;
             } else if (type == 1) {
-                if (iend - ip < 1) { r.rc = D_MALFORMED; fail = true; break; }
+                if (iend - ip < 1) { r.rc = SHORT; park(1, block_at); fail = true; break; }
                 if (bsize > (u64)(oend - op)) { r.rc = D_DST_FULL; fail = true; break; }
                 const u8 v = (u8)uld8(ip);
                 {
@@ -1262,7 +1317,8 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const
                 }
                 ip += 1; op += bsize;
             } else {
-                if (bsize > (u64)(iend - ip) || bsize >= ZSTD_BLOCK_MAX) { r.rc = D_MALFORMED; fail = true; break; }
+                if (bsize >= ZSTD_BLOCK_MAX) { r.rc = D_MALFORMED; fail = true; break; }
+                if (bsize > (u64)(iend - ip)) { r.rc = SHORT; park(1, block_at); fail = true; break; }
                 u64 got = 0;
                 int rc = zstd_block<EXEC_ONLY>(sh, fs, ip, bsize, iend, op, (u64)(oend - op), frame_lo, lit_buf, got, lane);
                 if (rc != D_OK) { r.rc = rc; fail = true; break; }
@@ -1275,13 +1331,15 @@ __device__ inline DecodeOut zstd_decode_wave(ZstdShared& sh, Watchdog& wd, const
         pre_idx = fs.pre_idx;
         if (fn != 0 && (u64)(op - frame_lo) != fcs) { r.rc = D_MALFORMED; break; }
         if (cksum) {
-            if (iend - ip < 4) { r.rc = D_MALFORMED; break; }
+            if (iend - ip < 4) { r.rc = SHORT; park(2, ip); break; }
             u32 h = 0;
             lane0_guard();
             if (lane == 0) h = (u32)xxh64_serial(frame_lo, (u64)(op - frame_lo), 0);
             if (uni(h) != uld32(ip)) { r.rc = D_MALFORMED; break; }
             ip += 4;
         }
+        // a frame is complete: a later call starts in front of the next one
+        if (rs) { lane0_guard(); if (lane == 0) { rs->phase = 0; rs->ip_off = (u64)(ip - src); rs->op_off = (u64)(op - dst); } }
     }
     r.produced = (u64)(op - dst);
     return r;
