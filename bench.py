@@ -386,7 +386,10 @@ def main():
             print("PARITY FAILURE rank %d: bad_status=%d hash_ok=%s size_ok=%s bytes_ok=%s" % (rank, bad, hash_ok, size_ok, bytes_ok),
                   file=sys.stderr)
 
-        k_ms = float(sum(stage_ms))
+        # mixed batches: the LZ4 kernels run on a side stream BESIDE the Zstandard stages (zpk_codec.hip), the stage times overlap —
+        # the kernel time of a launch is then the device time of the whole batch (HIP events on the launch stream, all timed steps)
+        overlapped = w["method"] < 0
+        k_ms = float(ev_ms / args.steps) if overlapped else float(sum(stage_ms))
         alg_bytes = my_comp + my_uncomp                                    # each byte moved once, this rank's launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         if rank == 0:
@@ -422,7 +425,9 @@ def main():
                              "kernel": "+".join((["k_lz4_wave"] if w["method"] < 0 else []) + KNAMES[kern]),
                              "kernel_ms": k_ms, "stage_ms": stage_ms,
                              "stage_names": (["k_lz4_wave"] if w["method"] < 0 else []) + {"lz4": ["k_lz4_wave"],
-                                             "zstd": ["k_zstd_fse", "k_zstd_exec+k_zstd"], "stored": ["k_stored"]}[kern], "kernel_ms_source": "HIP events around the kernels of the last timed step",
+                                             "zstd": ["k_zstd_fse", "k_zstd_exec+k_zstd"], "stored": ["k_stored"]}[kern],
+                             "kernel_ms_source": ("HIP events around the whole batch on the launch stream, mean over the timed steps: the LZ4 stage runs beside the "
+                                                  "Zstandard stages, stage_ms overlap") if overlapped else "HIP events around the kernels of the last timed step",
                              "algorithmic_bytes_per_launch": alg_bytes},
                 "decode_stats": dstats,
                 "cpu_baseline": cpu,
