@@ -433,6 +433,7 @@ struct zpk_codec {
     hipStream_t s_up = nullptr, s_dn = nullptr;  // host-pointer decode pipeline: upload / download streams beside `stream` (created on first use)
     hipStream_t s_side = nullptr;                // decode batches: the LZ4 kernel beside the Zstandard stages (low priority, created on first use)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    volatile u32* h_seen = nullptr;              // pinned: the work-list counts of an earlier device batch (what the next one probably holds)
     hipEvent_t pipe_ev[2 * 64] = {};             // per piece: uploaded, decoded
     u8*  d_dst = nullptr;        u64 dst_cap = 0;
     void* d_desc = nullptr;      u64 desc_cap = 0;
@@ -531,6 +532,7 @@ void zpk_codec_destroy(zpk_codec* c)
     (void)hipFree(c->d_counters); (void)hipFree(c->d_lists); (void)hipFree(c->d_lit);
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
     for (int k = 0; k < 2; k++) { if (c->h_pin[k]) (void)hipHostFree(c->h_pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
+    if (c->h_seen) (void)hipHostFree((void*)c->h_seen);
     if (c->s_side) (void)hipStreamDestroy(c->s_side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -623,8 +625,14 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     hipStream_t sl = st;
 #ifndef ZPK_NO_SIDE_STREAM
     // (measured, 125 000 mixed entries: 112.0 -> 90.9 ms per batch, the LZ4 kernel's 25 ms disappear inside the Zstandard stages, which
-    // get 1-3 ms longer; a pure LZ4 batch — the Zstandard kernels find empty lists — is unchanged within noise: 618.4 vs 618.2 GiB/s)
-    if (maybe_lz4 && maybe_zstd && !(skip & 6)) {
+    // get 1-3 ms longer; a pure LZ4 batch — the Zstandard kernels find empty lists — is unchanged within noise: 618.4 vs 618.2 GiB/s.)
+    // A device batch does not say which methods it holds, and a pure Zstandard batch must NOT take the side stream: k_lz4_wave is one
+    // workgroup per entry, and 100 000 EMPTY workgroups trickling through at low priority beside the pre-decode stage cost it 15 ms
+    // (71.9 -> 87.6 ms).  So the codec looks at the work-list counts of the batch BEFORE (copied to pinned memory behind every batch,
+    // no synchronisation): both methods there, or nothing known yet -> side stream; a codec fed batches of one method stays on one stream.
+    if (!c->h_seen && hipHostMalloc((void**)&c->h_seen, 64, hipHostMallocDefault) == hipSuccess) { c->h_seen[L_NONE] = 0; c->h_seen[L_ZSTD] = 1; c->h_seen[L_LZ4] = 1; }
+    const bool both_seen = c->zstd_hint >= 0 /* the host path knows */ || (c->h_seen && c->h_seen[L_ZSTD] != 0 && c->h_seen[L_LZ4] != 0);
+    if (maybe_lz4 && maybe_zstd && both_seen && !(skip & 6)) {
         int lo_prio = 0, hi_prio = 0;
         if (!c->s_side) { (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
                           if (hipStreamCreateWithPriority(&c->s_side, hipStreamNonBlocking, lo_prio) != hipSuccess) c->s_side = nullptr; }
@@ -695,6 +703,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
         }
     }
     ZPK_TRACE_STEP("retry");
+    if (c->h_seen && c->zstd_hint < 0) (void)hipMemcpyAsync((void*)c->h_seen, c->d_counters, N_LISTS * sizeof(u32), hipMemcpyDeviceToHost, st);
     HIPCHK(c, hipGetLastError());
     return ZPK_OK;
 }
