@@ -1,5 +1,5 @@
 """Developer aid: device compress throughput / ratio per class (source bytes resident in HBM).
-usage: python tools/enc_bench.py [n_entries] [entry_bytes]"""
+usage: python tools/enc_bench.py [n_entries] [entry_bytes] [level]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +9,7 @@ from benchdata import datagen as dg
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 codec = zpack_amd.Codec(0)
 dev = torch.device("cuda:0")
 for cls, cname in enumerate(["text", "records", "random", "runs"]):
@@ -23,7 +24,7 @@ for cls, cname in enumerate(["text", "records", "random", "runs"]):
         desc["dst_offset"] = np.arange(n, dtype=np.uint64) * ((bound + 255) & ~255)
         desc["dst_capacity"] = bound
         desc["method"] = method
-        desc["level"] = 1
+        desc["level"] = level
         ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
         dst = torch.empty(int(n * ((bound + 255) & ~255)), dtype=torch.uint8, device=dev)
         dres = torch.zeros(n * zpack_amd.ENCODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
