@@ -795,6 +795,56 @@ static int d2h_scatter(zpk_codec* c, const u8* d_base, u64 total, u64 n, uint8_t
     }
     return ZPK_OK;
 }
+
+// The other direction (round 3): entries that lie in the caller's (pageable, separate) buffers go up to the device range [d_base,
+// d_base + total) in pieces of ZPK_PIN_CHUNK bytes through the two pinned buffers — piece j + 1 is gathered by a few host threads
+// while piece j is on the bus.  Entry i owns bytes [off(i), off(i) + len(i)) of the range (ascending in i); the gaps between entries
+// carry whatever the staging buffer held.  (One hipMemcpyAsync per entry out of pageable memory: 40 000 x 64 KiB took 0.5 s.)
+template <class OffFn, class LenFn>
+static int h2d_gather(zpk_codec* c, u8* d_base, u64 total, u64 n, const uint8_t* const* src_ptrs, OffFn off, LenFn len, hipError_t& e, hipStream_t st)
+{
+    int rc = pin_ready(c);
+    if (rc) return rc;
+    e = hipSuccess;
+    if (total == 0) return ZPK_OK;
+    const u64 npieces = (total + ZPK_PIN_CHUNK - 1) / ZPK_PIN_CHUNK;
+    u64 ei = 0;
+    bool used[2] = { false, false };
+    for (u64 j = 0; j < npieces && e == hipSuccess; j++) {
+        const int k = (int)(j & 1);
+        const u64 p0 = j * ZPK_PIN_CHUNK, p1 = p0 + ZPK_PIN_CHUNK < total ? p0 + ZPK_PIN_CHUNK : total;
+        if (used[k]) { e = hipEventSynchronize(c->pin_ev[k]); if (e != hipSuccess) break; }      // the buffer's previous piece has left
+        while (ei < n && off(ei) + len(ei) <= p0) ei++;
+        u64 ej = ei;
+        while (ej < n && off(ej) < p1) ej++;
+        auto part = [&](u64 lo_i, u64 hi_i) {
+            for (u64 i = lo_i; i < hi_i; i++) {
+                const u64 o = off(i), l = len(i);
+                const u64 a = o > p0 ? o : p0, z = o + l < p1 ? o + l : p1;
+                if (z > a) memcpy(c->h_pin[k] + (a - p0), src_ptrs[i] + (a - o), z - a);
+            }
+        };
+        const u64 cnt = ej - ei;
+        const unsigned T = (p1 - p0 >= (4u << 20) && cnt >= 8) ? ZPK_SCATTER_THREADS : 1u;
+        if (T <= 1) part(ei, ej);
+        else {
+            std::thread th[ZPK_SCATTER_THREADS - 1];
+            bool started[ZPK_SCATTER_THREADS - 1] = {};
+            for (unsigned t = 1; t < T; t++) {
+                try { th[t - 1] = std::thread(part, ei + cnt * t / T, ei + cnt * (t + 1) / T); started[t - 1] = true; }
+                catch (...) { started[t - 1] = false; }
+            }
+            part(ei, ei + cnt / T);
+            for (unsigned t = 1; t < T; t++) { if (started[t - 1]) th[t - 1].join(); else part(ei + cnt * t / T, ei + cnt * (t + 1) / T); }
+        }
+        e = hipMemcpyAsync(d_base + p0, c->h_pin[k], p1 - p0, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(c->pin_ev[k], st);
+        used[k] = true;
+    }
+    // the pinned buffers serve the download next: both uploads have to be off them
+    for (int k = 0; k < 2 && e == hipSuccess; k++) if (used[k]) e = hipEventSynchronize(c->pin_ev[k]);
+    return ZPK_OK;
+}
 }  // extern "C++"
 
 static int decode_host_chunk(zpk_codec* c, const u8* image, u64 image_size, u64 lo, u64 hi, zpk_decode_desc* hd,
