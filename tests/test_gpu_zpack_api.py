@@ -233,6 +233,20 @@ def test_batch_write_then_batch_read_roundtrip(Z, method, level):
     Z.close_reader(r)
 
 
+def test_batch_write_spans_staging_pieces(Z):
+    """zpack_write_files with entries larger than, and straddling, the 32 MiB pinned staging pieces the sources are gathered into on
+    their way up (h2d_gather) and the payloads come back through (d2h_scatter): every entry decodes back to its source."""
+    sizes = [40 << 20, 7, 0, (30 << 20) + 13, 1 << 20, 65537, (33 << 20) + 1, 12345]
+    want = [("g%02d" % i, dg.fill(i % 2, 91, i, n).tobytes()) for i, n in enumerate(sizes)]
+    arc = Z.write_archive(want, METHOD_LZ4, 0)
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0 and r.file_count == len(want)
+    for i, (name, d) in enumerate(want):
+        rc, out = Z.read_file(r, i, max(1, len(d)))
+        assert rc == 0 and out[:len(d)] == d, (name, rc)
+    Z.close_reader(r)
+
+
 @pytest.mark.parametrize("method,level", [(METHOD_ZSTD, 1), (METHOD_LZ4, 0)])
 def test_encoder_stress_alphabets_and_boundaries(Z, method, level):
     """Inputs aimed at the device encoders' corner cases — literal-heavy data over alphabets of 2..129 symbols with
