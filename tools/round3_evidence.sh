@@ -2,7 +2,7 @@
 # Round-3 evidence on the GPU box, in parts (gpurun calls are limited to 20 minutes): tools/round3_evidence.sh <part> [tag]
 #   a: GPU tests + smoke + C2 (kernel trace, PMC passes, then the default bench line that quotes them)
 #   b: C3 (bench, trace, PMC) + C4 bench + 2-rank rehearsal
-#   c: C5 (bench, trace at 12 500 entries, PMC) + host-pointer rates
+#   c: host-pointer rates (read and write path), C5 (bench, trace at 12 500 entries, PMC), encode rate per class at levels 1 and 3
 #   d: fuzz (damaged frames, LZ4 + Zstandard)
 # Everything lands under gpurun_out/<tag>/; the PMC summaries are also copied to profiles/<tag>/ ON THE BOX so that the bench lines quote them.
 part=${1:-a}; tag=${2:-r03}
@@ -33,10 +33,12 @@ b)
   timeout -k 10 900 python bench.py --workload c4_mixed --steps 3 --warmup 1 > $out/${tag}_c4_mixed_bench.json 2> $out/c4.err; echo "bench c4 rc=$?"; line c4_mixed
   timeout -k 10 600 python bench.py --gpus 2 --workload c4_mixed --entries 30000 --steps 3 --warmup 1 --no-cpu > $out/${tag}_c4_strong_2rank_rehearsal.json 2> $out/strong.err; echo "2-rank rc=$?"; cut -c1-300 $out/${tag}_c4_strong_2rank_rehearsal.json ;;
 c)
+  { python3 tools/host_rate.py 20000 2 2>&1 | tail -2; python3 tools/host_rate.py 60000 2 2>&1 | tail -1; python3 tools/host_rate.py 8000 1 2>&1 | tail -1; } | tee $out/${tag}_host_rate.txt
+  { python3 tools/host_write_rate.py 4000 1048576 1 1 2>&1 | grep -v amdgpu.ids | tail -3; python3 tools/host_write_rate.py 40000 65536 2 0 2>&1 | grep -v amdgpu.ids | tail -3; } | tee $out/${tag}_host_write_rate.txt
   trace c5_zstd1 --workload c5_zstd1_1m --steps 2 --warmup 1
   pmc2 c5 c5_zstd1_1m 12500 --workload c5_zstd1_1m
   timeout -k 10 1100 python bench.py --workload c5_zstd1_1m --steps 3 --warmup 1 > $out/${tag}_c5_zstd1_bench.json 2> $out/c5.err; echo "bench c5 rc=$?"; line c5_zstd1
-  { python3 tools/host_rate.py 20000 2 2>&1 | tail -2; python3 tools/host_rate.py 60000 2 2>&1 | tail -1; python3 tools/host_rate.py 8000 1 2>&1 | tail -1; } | tee $out/${tag}_host_rate.txt ;;
+  { timeout -k 10 300 python3 tools/enc_bench.py 4000 1048576 1 2>&1 | grep -E "^(text|records|random|runs) "; timeout -k 10 300 python3 tools/enc_bench.py 2000 1048576 3 2>&1 | grep -E "^(text|records|random|runs) "; } | tee $out/${tag}_enc_classes_levels.txt ;;
 d)
   timeout -k 10 1100 python3 tools/fuzz_gpu.py 400 11 all > $out/${tag}_fuzz_all.log 2>&1; echo "fuzz rc=$?"; tail -8 $out/${tag}_fuzz_all.log ;;
 esac
