@@ -179,7 +179,8 @@ def test_c5_config_zstd1_one_mib_sources(Z):
     by_class = {}
     for e, (n, d) in zip(ents, want):
         by_class.setdefault(int(n.split("_")[1]), []).append(e["comp_size"] / len(d))
-    assert max(by_class[dg.TEXT]) < 0.40 and max(by_class[dg.RECORDS]) < 0.60 and max(by_class[dg.RUNS]) < 0.15, by_class     # (libzstd-1: 0.014 on runs — the 64-position chunked parse cuts long matches)
+    # records / runs: the repeat-offset search (round 3) — without it 0.559 / 0.107; libzstd-1: 0.506 / 0.014
+    assert max(by_class[dg.TEXT]) < 0.40 and max(by_class[dg.RECORDS]) < 0.53 and max(by_class[dg.RUNS]) < 0.05, by_class
     assert max(by_class[dg.RANDOM]) < 1.001                          # raw blocks: never larger than the frame overhead
     rc, r, keep = Z.open_memory(arc)
     assert rc == 0
