@@ -234,6 +234,22 @@ def test_batch_write_then_batch_read_roundtrip(Z, method, level):
     Z.close_reader(r)
 
 
+@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 1), (METHOD_ZSTD, 3)])
+def test_encoder_long_literal_runs(Z, method, level):
+    """Blocks that hold a few sequences with literal runs of tens of KiB (random bytes, a 64-byte marker every `gap` bytes): the runs beyond
+    256 bytes are copied by the whole wave in the LZ4 block writer and in the Zstandard literal gather; lengths around the switch too."""
+    rng = np.random.default_rng(11)
+    want = []
+    for i, gap in enumerate([30000, 3000, 700, 300, 257, 256, 255, 97]):
+        a = rng.integers(0, 256, (1 << 18) + 13 * i, dtype=np.uint8)
+        mk = rng.integers(0, 256, 64, dtype=np.uint8)
+        for p in range(gap, len(a) - 64, gap + 64):
+            a[p:p + 64] = mk
+        want.append(("ll%02d" % i, a.tobytes()))
+    arc = Z.write_archive(want, method, level)
+    _decode_all_with_checkers(arc, want)
+
+
 def test_batch_write_spans_staging_pieces(Z):
     """zpack_write_files with entries larger than, and straddling, the 32 MiB pinned staging pieces the sources are gathered into on
     their way up (h2d_gather) and the payloads come back through (d2h_scatter): every entry decodes back to its source."""
