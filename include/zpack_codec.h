@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ZPK_CODEC_ABI_VERSION 1
+#define ZPK_CODEC_ABI_VERSION 2      /* 2: set_option has options again, decode_stats2 out[2..4], ZPK_K_LZ4_PARSE */
 
 /* return codes of the zpk_* entry points themselves (not per-entry statuses) */
 enum {
@@ -108,8 +108,17 @@ void        zpk_codec_destroy(zpk_codec* c);
 void        zpk_codec_reset(zpk_codec* c);                  /* after an abandoned stream / error */
 const char* zpk_codec_last_error(const zpk_codec* c);
 int         zpk_codec_device(const zpk_codec* c);
-/* options: none at present — every call returns ZPK_E_INVALID (round 2's ZPK_OPT_LZ4_RING path lost to the default decoder on every
- * corpus class and was removed in round 3; the entry point stays so that the ABI does not shrink) */
+/* options (ZPK_E_INVALID for anything else):
+ *   ZPK_OPT_LZ4_TWO_STAGE_MIN       decode batches of at least `value` entries run their LZ4 entries in two stages — token chains one
+ *                                   LANE per entry, then execution one wave per entry from the records (lz4_two.h); smaller batches
+ *                                   take the one-kernel decoder.  0 = every batch, INT_MAX = never = the DEFAULT: on the headline
+ *                                   workload the path measured slower than the one-kernel decoder (profiles/r04).
+ *   ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP  ... for entries of at most `value` compressed bytes (one lane walks one entry; longer entries
+ *                                   stay with the one-wave decoder).  Default 96 KiB.
+ * The results are identical either way (every irregular entry is decoded by the general decoder, which alone gives verdicts). */
+enum { ZPK_OPT_LZ4_TWO_STAGE_MIN = 2, ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP = 3,
+       ZPK_OPT_LZ4_EXEC_WINDOW = 5 /* stage 2 of the two-stage path: 1 = output assembled in an LDS window, 0 = in the output slot */,
+       ZPK_OPT_DEV_LZ4_EXEC_PAD = 4 /* measurement aid: bytes of idle LDS per stage-2 workgroup, i.e. fewer entries in flight per CU */ };
 int         zpk_codec_set_option(zpk_codec* c, int option, int value);
 
 /* ---- batch decode + verify ----------------------------------------------------------------
@@ -162,11 +171,12 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
  * with HIP events on the launch stream; zpk_codec_kernel_ms then returns the duration of kernel
  * `which` (ZPK_K_*) in the most recent batch (synchronises on that batch). */
 enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2 /* k_lz4_wave */, ZPK_K_ZSTD = 3 /* k_zstd_exec + k_zstd */, ZPK_K_ZSTD_FSE = 4,
-       ZPK_K_PACK = 5, ZPK_K_RESERVED6 = 6, ZPK_K_ENCODE = 7, ZPK_K_COUNT = 8 };
+       ZPK_K_PACK = 5, ZPK_K_LZ4_PARSE = 6 /* k_lz4_parse, inside ZPK_K_LZ4's bracket */, ZPK_K_ENCODE = 7, ZPK_K_COUNT = 8 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
 /* out[0], out[1] = LZ4 / Zstandard entries of the most recent decode batch whose first decode ran out of its time budget (a
  * contended or preempted GPU) and that were decoded again, behind the batch, with a 64 x larger one — a slow wave is not a
- * verdict; expected 0 on an idle GPU */
+ * verdict; expected 0 on an idle GPU.  out[2], out[3] = LZ4 entries finished by the two-stage path / handed by it to the general
+ * decoder; out[4] = 1 when the batch took the two-stage path at all */
 int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16]);
 /* counters of the most recent decode batch (synchronises): out[0..2] = entries on the stored / zstd / lz4 work
  * lists, out[3] = Zstandard entries finished on pre-decoded sequences (two-stage path), out[4] = by the fused decoder,

@@ -24,7 +24,7 @@ def test_codec_library_exports_every_declared_symbol():
     assert len(names) >= 25
     assert [n for n in names if " T " + n not in syms] == []
     lib = C.CDLL(zpack_amd.CODEC_SO)
-    assert lib.zpk_codec_abi_version() == 1
+    assert lib.zpk_codec_abi_version() == 2
 
 
 def test_zpack_library_exports_the_reference_api():

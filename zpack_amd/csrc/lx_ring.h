@@ -22,8 +22,6 @@ namespace zpk {
 #define LX_RING 4096u                        // bytes of output kept in LDS: abs positions [rb, rb + LX_RING), rb a multiple of 1 KiB
 #endif
 #define LX_HIST 1024u                        // a slide keeps at least this much flushed history (>= LX_MAX_ML: a source is all-ring or all-memory)
-static_assert(LX_RING - LX_HIST - 1023u >= LX_MAX_LL + LX_MAX_ML, "one sequence always fits behind a slide");
-static_assert(LX_HIST >= LX_MAX_ML, "an overlapping match's source is always in the ring");
 
 
 
@@ -35,7 +33,13 @@ enum { LX_OK = 0, LX_E_FRAME = 1, LX_E_LIST = 2, LX_E_TOKEN = 3, LX_E_OFFSET = 4
 #else
 #define LXT(slot) do { } while (0)
 #endif
-struct LxOut {
+// RING_ bytes of output kept in LDS; a slide keeps at least HIST_ bytes of flushed history.  The Zstandard execute stage uses
+// LxOut = <LX_RING, LX_HIST>; the LZ4 window executor (lz4_two.h) a larger ring.
+template <u32 RING_, u32 HIST_>
+struct LxOutT {
+    static constexpr u32 RING = RING_, HIST = HIST_;
+    static_assert(RING_ - HIST_ - 1023u >= LX_MAX_LL + LX_MAX_ML, "one sequence always fits behind a slide");
+    static_assert(HIST_ >= LX_MAX_ML, "an overlapping match's source is always in the ring");
 #ifdef LX_STATS
     u64 tm[12]; u64 t_last;      // developer: cycles per phase (wait, prefetch, decode, scan, deps, lit, match, rounds, flush, slide, other)
 #endif
@@ -46,6 +50,7 @@ struct LxOut {
     lds_cp8 sec;         // the XXH3 secret in LDS (192 bytes), or null: constant memory
     Xxh3Lite xs;
 };
+typedef LxOutT<LX_RING, LX_HIST> LxOut;
 
 // LDS accesses here are 8-byte ALIGNED only.  Measured (rocprofv3, round 2): with 16-byte reads and 2/4/8-byte stores at
 // arbitrary byte addresses the kernel was bound by the LDS itself — SQ_LDS_UNALIGNED_STALL 1.2e9 and SQ_LDS_IDX_ACTIVE 1.9e9 of
@@ -85,18 +90,20 @@ __device__ __forceinline__ void lds_or_piece(lds_p8 base, u32 pos, u128 v, u32 n
 }
 
 // 16 bytes of OUTPUT at abs position s: from the ring when they are there, else from memory (flushed long ago)
-__device__ __forceinline__ u128 lx_load16(const LxOut& O, u32 s)
+template <class OT>
+__device__ __forceinline__ u128 lx_load16(const OT& O, u32 s)
 {
     u128 v;
 #ifdef LX_ABL_NOGATHER
-    return lds_ld16_any((lds_cp8)O.ring, (s - O.rb) & (LX_RING - 1));
+    return lds_ld16_any((lds_cp8)O.ring, (s - O.rb) & (OT::RING - 1));
 #endif
     if (s >= O.rb) v = lds_ld16_any((lds_cp8)O.ring, s - O.rb);
     else v = ld128(O.dst + s);
     return v;
 }
 
-__device__ __forceinline__ void lx_flush_blocks(LxOut& O, int lane)
+template <class OT>
+__device__ __forceinline__ void lx_flush_blocks(OT& O, int lane)
 {
     while (O.fp + 1024u <= O.wp) {
         const u128 v = lds_ld128((lds_cp8)(O.ring + (O.fp - O.rb) + 16u * (u32)lane));
@@ -110,11 +117,12 @@ __device__ __forceinline__ void lx_flush_blocks(LxOut& O, int lane)
     }
 }
 
-// make the ring hold [rb', wp) with rb' = fp - LX_HIST: afterwards at least LX_RING - LX_HIST - 1023 bytes are free
-__device__ __forceinline__ void lx_slide(LxOut& O, int lane)
+// make the ring hold [rb', wp) with rb' = fp - OT::HIST: afterwards at least OT::RING - OT::HIST - 1023 bytes are free
+template <class OT>
+__device__ __forceinline__ void lx_slide(OT& O, int lane)
 {
     lx_flush_blocks(O, lane);
-    const u32 nrb = O.fp >= LX_HIST ? O.fp - LX_HIST : 0u;
+    const u32 nrb = O.fp >= OT::HIST ? O.fp - OT::HIST : 0u;
     if (nrb > O.rb) {
         const u32 shift = nrb - O.rb, n = O.wp - nrb;
         for (u32 c = 16u * (u32)lane; c < n; c += 1024u) {        // rounds in order: a round only overwrites what earlier rounds have read
@@ -129,12 +137,13 @@ __device__ __forceinline__ void lx_slide(LxOut& O, int lane)
 }
 
 // `n` raw bytes from memory appended to the output (stored LZ4 blocks)
-__device__ inline int lx_append_raw(LxOut& O, const u8* s, u64 n, const u8* read_hi, u64 dst_cap, int lane)
+template <class OT>
+__device__ inline int lx_append_raw(OT& O, const u8* s, u64 n, const u8* read_hi, u64 dst_cap, int lane)
 {
     if ((u64)O.wp + n > dst_cap) return LX_E_CAPACITY;
     while (n) {
         u32 m = n < 1024u ? (u32)n : 1024u;
-        if (O.wp + m > O.rb + LX_RING) lx_slide(O, lane);
+        if (O.wp + m > O.rb + OT::RING) lx_slide(O, lane);
         const u32 c = 16u * (u32)lane;
         {
             u128 v; v.lo = 0; v.hi = 0;
@@ -152,13 +161,14 @@ __device__ inline int lx_append_raw(LxOut& O, const u8* s, u64 n, const u8* read
 }
 
 // `n` copies of one byte appended to the output (Zstandard RLE blocks / RLE literals)
-__device__ inline int lx_append_fill(LxOut& O, u32 byte, u64 n, u64 dst_cap, int lane)
+template <class OT>
+__device__ inline int lx_append_fill(OT& O, u32 byte, u64 n, u64 dst_cap, int lane)
 {
     if ((u64)O.wp + n > dst_cap) return LX_E_CAPACITY;
     u128 pat; pat.lo = 0x0101010101010101ull * (u64)(byte & 0xFFu); pat.hi = pat.lo;
     while (n) {
         const u32 m = n < 1024u ? (u32)n : 1024u;
-        if (O.wp + m > O.rb + LX_RING) lx_slide(O, lane);
+        if (O.wp + m > O.rb + OT::RING) lx_slide(O, lane);
         const u32 c = 16u * (u32)lane;
         lds_or_piece(O.ring, (O.wp - O.rb) + (c < m ? c : 0u), pat, c < m ? (m - c < 16u ? m - c : 16u) : 0u);
         wave_mem_fence();
@@ -170,7 +180,8 @@ __device__ inline int lx_append_fill(LxOut& O, u32 byte, u64 n, u64 dst_cap, int
 
 // a match of ANY length appended to the output: out[i] = out[i - off].  Everything from (match start - off) on is periodic with period
 // off, so every step copies from the largest multiple of off that is already there (<= 1 KiB): the step size doubles until it is 1 KiB
-__device__ inline int lx_append_match(LxOut& O, u32 off, u64 n, u32 hist_lo, u64 dst_cap, int lane)
+template <class OT>
+__device__ inline int lx_append_match(OT& O, u32 off, u64 n, u32 hist_lo, u64 dst_cap, int lane)
 {
     if (off == 0 || off > O.wp - hist_lo) return LX_E_OFFSET;
     if ((u64)O.wp + n > dst_cap) return LX_E_CAPACITY;
@@ -184,7 +195,7 @@ __device__ inline int lx_append_match(LxOut& O, u32 off, u64 n, u32 hist_lo, u64
             D = cap / off * off;                                                 // >= off
             m = n < D ? (u32)n : D;
         }
-        if (O.wp + m > O.rb + LX_RING) lx_slide(O, lane);
+        if (O.wp + m > O.rb + OT::RING) lx_slide(O, lane);
         const u32 s = O.wp - D;
         if (m >= 16u) {
             const u32 c = 16u * (u32)lane;
@@ -222,8 +233,8 @@ struct LxLitFill {
 // ring's write position: output positions (prefix sum), in-batch dependencies, literals and matches OR-ed into the ring, whole
 // 1 KiB blocks flushed (and hashed).  cnt may come back SMALLER: a batch whose output does not fit the ring is cut (the caller goes
 // on behind the sequences taken).  Lengths must be <= LX_MAX_LL / LX_MAX_ML.  hist_lo = lowest abs output position a match may reach.
-template <class LitSrc>
-__device__ __forceinline__ int lx_exec_batch(LxOut& O, u32& cnt, u32 ll, u32 ml, u32 off, const LitSrc& L, u32 hist_lo, u64 dst_cap,
+template <class OT, class LitSrc>
+__device__ __forceinline__ int lx_exec_batch(OT& O, u32& cnt, u32 ll, u32 ml, u32 off, const LitSrc& L, u32 hist_lo, u64 dst_cap,
                                              int lane, SeqStats& stt)
 {
     bool act = (u32)lane < cnt;
@@ -231,9 +242,9 @@ __device__ __forceinline__ int lx_exec_batch(LxOut& O, u32& cnt, u32 ll, u32 ml,
     // ---- output positions ----
     u32 x = wave_scan_add(ll + ml);
     u32 total = (u32)__builtin_amdgcn_readlane((int)x, 63);
-    if (O.wp + total > O.rb + LX_RING) {                 // (only a batch of more than 2 KiB of output gets here)
+    if (O.wp + total > O.rb + OT::RING) {                 // (only a batch of more than 2 KiB of output gets here)
         lx_slide(O, lane);
-        const u32 free_ = O.rb + LX_RING - O.wp;
+        const u32 free_ = O.rb + OT::RING - O.wp;
         if (total > free_) {                         // take the sequences that fit; the rest next time round
             const u32 c2 = (u32)__popcll(__ballot(act && x <= free_));
             if (c2 == 0) return LX_E_FIT;
@@ -370,11 +381,12 @@ __device__ __forceinline__ int lx_exec_batch(LxOut& O, u32& cnt, u32 ll, u32 ml,
 struct LxResult { int rc; u64 produced; u64 hash; };
 
 // init / finish of an entry's ring
-__device__ __forceinline__ void lx_begin(LxOut& O, lds_p8 ring, u8* dst, u64 uncomp_size, int lane, lds_p8 sec = nullptr)
+template <class OT>
+__device__ __forceinline__ void lx_begin(OT& O, lds_p8 ring, u8* dst, u64 uncomp_size, int lane, lds_p8 sec = nullptr)
 {
     O.ring = ring; O.dst = dst; O.sec = (lds_cp8)sec;
     if (sec && lane < 12) lds_st128(sec + 16 * lane, ld128(XXH3_SECRET + 16 * lane));
-    for (u32 c = 16u * (u32)lane; c < LX_RING + 32u; c += 1024u) { u128 z; z.lo = 0; z.hi = 0; lds_st128(O.ring + c, z); }     // ring bytes >= wp are zero, always
+    for (u32 c = 16u * (u32)lane; c < OT::RING + 32u; c += 1024u) { u128 z; z.lo = 0; z.hi = 0; lds_st128(O.ring + c, z); }     // ring bytes >= wp are zero, always
     wave_mem_fence();
     O.wp = 0; O.rb = 0; O.fp = 0;
     O.hash_blocks = uncomp_size > 240 ? (u32)((uncomp_size - 1) >> 10) : 0u;
@@ -382,7 +394,8 @@ __device__ __forceinline__ void lx_begin(LxOut& O, lds_p8 ring, u8* dst, u64 unc
 }
 // the tail (what is left of the last 1 KiB block, exact to the byte), then XXH3 of dst[0, uncomp_size) (lib/zpack_read.c:466): fused
 // when the entry produced exactly that many bytes, by re-reading otherwise
-__device__ __forceinline__ void lx_finish(LxOut& O, u8* dst, u64 uncomp_size, LxResult& R, int lane)
+template <class OT>
+__device__ __forceinline__ void lx_finish(OT& O, u8* dst, u64 uncomp_size, LxResult& R, int lane)
 {
     lx_flush_blocks(O, lane);
     {
