@@ -169,6 +169,16 @@ def _visible_gpus():
     vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
     if vis is not None and vis.strip() != "":
         n = min(n, len([x for x in vis.split(",") if x.strip() != ""])) if n else len([x for x in vis.split(",") if x.strip() != ""])
+    if n == 0:
+        # sysfs says nothing (a container without /sys/class/kfd): that is "unknown", not "no GPU" — ask the runtime, in a short-lived
+        # CHILD process (this one must not initialise HIP: it only spawns the ranks)
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, text=True, timeout=300)
+            n = int(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            return None
     return n
 
 
@@ -179,6 +189,8 @@ def spawn_ranks(n, argv):
     have = _visible_gpus()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if have is None:
+        have = n                     # unknown: no rehearsal is forced; every rank checks torch.cuda.device_count() itself and fails there
     if have < n:
         if n > 4:
             print("bench.py: --gpus %d asked for, %d GPU(s) visible: a rehearsal on one card is limited to 4 ranks" % (n, have), file=sys.stderr)
@@ -247,6 +259,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not rehearsal and local_rank >= torch.cuda.device_count():
+        print("bench.py: rank %d wants cuda:%d, %d device(s) visible" % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -342,7 +342,9 @@ def _stream_entry(Z, r, i, in_window, out_window, sink):
     e = r.file_entries[i]
     Z.lib.zpack_reset_stream(C.byref(st))
     rss0, rss_peak, first_out_in, pos, rc = _rss_bytes(), 0, None, 0, 0
+    idle = 0
     for _ in range(10_000_000):
+        before_in = st.total_in
         if st.read_back:
             tail = C.string_at(C.addressof(st.next_in.contents) - st.read_back, st.read_back)
             C.memmove(in_buf, tail, st.read_back)
@@ -357,6 +359,9 @@ def _stream_entry(Z, r, i, in_window, out_window, sink):
             pos += got
         rss_peak = max(rss_peak, _rss_bytes() - rss0)
         if rc not in (0,) or (st.total_in == e.comp_size and st.total_out == e.uncomp_size and st.read_back == 0):
+            break
+        idle = idle + 1 if (got == 0 and st.total_in == before_in) else 0
+        if idle >= 3:                            # (an entry whose header claims more output than its frame holds: nothing more will come)
             break
     Z.lib.zpack_close_stream(C.byref(st))
     return rc, first_out_in, rss_peak, pos
@@ -391,3 +396,43 @@ def test_stream_read_is_bounded_and_incremental(Z, golden_dir, label):
     assert first_out_in < len(frame) // 8
     if len(frame) >= (128 << 20):                                                         # (smaller entries drown in allocator noise)
         assert rss_peak < (64 << 20), (rss_peak, len(frame))                              # no host copy of the compressed entry, let alone the output
+
+
+@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 3), (METHOD_NONE, 0)])
+@pytest.mark.parametrize("claimed", [(1 << 64) - 1, 0xAAAAAAAAAAAAA000, (1 << 64) - 64, 1 << 47])
+def test_stream_read_survives_lying_entry_sizes(Z, method, level, claimed):
+    """comp_size / uncomp_size reach zpack_read_file_stream from the CDR, unverified (lib/zpack_read.c:515-640 never trusts them for a
+    size computation of its own either: its library streams into the caller's window).  A stream must never size a device buffer
+    from them: an entry that CLAIMS 2^64 - 1 output bytes (or a value whose 1.5 x wraps to a few KiB) decodes what its frame
+    really holds — every byte right — and ends with the verdict of a frame that stops short of the claim; nothing is written or
+    read out of bounds, nothing allocates the claim."""
+    size = 300000
+    plain = dg.fill(dg.TEXT, 17, 0, size)
+    frame = plain.tobytes() if method == METHOD_NONE else bytes(dg.compress(method, level, plain))
+    arc = zpk.assemble([frame], [("liar", 10, len(frame), size, dg.xxh3(plain), method)])
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    r.file_entries[0].uncomp_size = claimed
+    sink = np.zeros(size + (1 << 20), dtype=np.uint8)
+    rc, first_out_in, rss_peak, got = _stream_entry(Z, r, 0, 131075, 1 << 20, sink)
+    Z.lib.zpack_close_reader(C.byref(r))
+    if method == METHOD_NONE:
+        assert rc == 18, rc                         # ZPACK_ERROR_FILE_SIZE_INVALID: lib/zpack_read.c:539 (uncomp_size > comp_size)
+    else:
+        # the frame is complete after `size` bytes: the hash of the PRODUCED bytes is right, total_out never reaches the claim —
+        # the caller's loop ends on the verdict or on input exhaustion; what matters here: the bytes, and no fault
+        assert rc in (0, 15, 17, 13), rc
+        assert got == size and np.array_equal(sink[:size], plain)
+    # and a comp_size beyond anything a device holds is refused before any arithmetic on it
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    r.file_entries[0].comp_size = claimed
+    st = Stream()
+    assert Z.lib.zpack_init_stream(C.byref(st)) == 0
+    in_buf = (C.c_uint8 * 4096)(); out_buf = (C.c_uint8 * 4096)()
+    st.next_in = C.cast(in_buf, u8p); st.avail_in = 4096
+    st.next_out = C.cast(out_buf, u8p); st.avail_out = 4096
+    rc = Z.lib.zpack_read_file_stream(C.byref(r), C.byref(r.file_entries[0]), C.byref(st), None)
+    assert rc != 0, rc                              # FILE_OFFSET_INVALID (the reader's own guard) or MALLOC_FAILED — never a decode
+    Z.lib.zpack_close_stream(C.byref(st))
+    Z.lib.zpack_close_reader(C.byref(r))

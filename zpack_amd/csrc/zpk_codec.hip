@@ -598,6 +598,11 @@ struct zpk_codec {
     int profiling = 0;
     int zstd_hint = -1;          // host path: does the batch hold a Zstandard entry (1 / 0)?  -1 = unknown (device path)
     int fell_back_fused = 0;     // the last decode batch could not get its sequence arena and ran the fused decoder only
+    // the host-path pipeline decodes one call in several launches: their counters are brought back piece by piece and summed, so that
+    // decode_stats / decode_stats2 describe the whole call (a retry or watchdog event in an early piece is not lost)
+    u32 piece_counters[64][N_COUNTERS] = {};
+    u32 host_totals[N_COUNTERS] = {};
+    int totals_valid = 0;
     char err[256] = {0};
 };
 
@@ -729,6 +734,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
 {
     if (n == 0) return ZPK_OK;
     if (n > 0x7FFFFFF0ull) return ZPK_E_INVALID;               // one workgroup per LZ4 entry: the grid's x limit
+    c->totals_valid = 0;                                        // (the pipeline sets it again once it has summed its pieces)
     int rc;
     if ((rc = grow(c, (void**)&c->d_lists, &c->list_cap, N_LISTS_ALLOC * n * sizeof(u32)))) return rc;
     const u64 stride = c->list_cap / (N_LISTS_ALLOC * sizeof(u32));
@@ -1145,6 +1151,7 @@ static int decode_host_pipelined(zpk_codec* c, const u8* image, u64 image_size, 
             if (lrc == ZPK_OK)
                 lrc = decode_launch(c, base, image_size, c->d_src + (P.clo - lo), c->d_src + (P.chi - lo), (const zpk_decode_desc*)c->d_desc + P.e0,
                                     P.e1 - P.e0, c->d_dst, out_total, (zpk_decode_result*)c->d_res + P.e0, c->stream);
+            if (lrc == ZPK_OK && hipMemcpyAsync(c->piece_counters[k], c->d_counters, N_COUNTERS * sizeof(u32), hipMemcpyDeviceToHost, c->stream) != hipSuccess) lrc = ZPK_E_LAUNCH;
             if (lrc == ZPK_OK && hipEventRecord(c->pipe_ev[2 * k + 1], c->stream) != hipSuccess) lrc = ZPK_E_LAUNCH;
             if (lrc != ZPK_OK) { launch_rc.store(lrc); launched.store(-1); return; }
             launched.store(k + 1);
@@ -1183,6 +1190,11 @@ static int decode_host_pipelined(zpk_codec* c, const u8* image, u64 image_size, 
     else if (rc == ZPK_OK && e != hipSuccess) { snprintf(c->err, sizeof(c->err), "host decode pipeline: %s", hipGetErrorString(e)); rc = ZPK_E_LAUNCH; }
     if (rc != ZPK_OK) { (void)hipStreamSynchronize(c->s_up); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_dn); }
     for (u64 i = 0; i < n && rc == ZPK_OK; i++) if (results[i].produced > desc[i].dst_capacity) results[i].produced = desc[i].dst_capacity;     // (cannot happen)
+    if (rc == ZPK_OK && hipStreamSynchronize(c->stream) == hipSuccess) {
+        memset(c->host_totals, 0, sizeof(c->host_totals));
+        for (int k = 0; k < np; k++) for (int w = 0; w < N_COUNTERS; w++) c->host_totals[w] += c->piece_counters[k][w];
+        c->totals_valid = 1;
+    }
     return rc;
 }
 
@@ -1304,6 +1316,7 @@ int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8])
     HIPCHK(c, hipDeviceSynchronize());
     u32 h[N_COUNTERS];
     HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    if (c->totals_valid) memcpy(h, c->host_totals, sizeof(h));          // a pipelined host batch: the sum over its launches
     out[0] = h[L_NONE]; out[1] = h[L_ZSTD]; out[2] = h[L_LZ4]; out[3] = h[C_ZSTD_TWO_STAGE]; out[4] = h[C_ZSTD_FUSED];
     out[5] = h[ZF_WATCHDOG_WORD]; out[6] = h[ZF_WATCHDOG_WORD + 1]; out[7] = h[13];
     if (c->fell_back_fused) out[7] |= 0x80000000u;          // the batch could not get its sequence arena: fused decoder only
@@ -1321,6 +1334,7 @@ int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
     HIPCHK(c, hipDeviceSynchronize());
     u32 h[N_COUNTERS];
     HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    if (c->totals_valid) memcpy(h, c->host_totals, sizeof(h));
     memset(out, 0, 16 * sizeof(uint32_t));
     out[0] = h[C_RETRY_LZ4]; out[1] = h[C_RETRY_ZSTD];
     out[2] = h[C_LZ4_TWO_OK]; out[3] = h[C_LZ4_LEFT]; out[4] = (u32)c->lz4_two_last;

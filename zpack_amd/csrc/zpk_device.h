@@ -176,7 +176,8 @@ struct Watchdog {
     u64 deadline; u32 tick; bool fired;
     __device__ __forceinline__ void arm(u64 bytes, u32 scale = 1u)
     {
-        deadline = __builtin_amdgcn_s_memrealtime() + watchdog_budget(bytes) * (u64)scale; tick = 0; fired = false;
+        const u64 b = watchdog_budget(bytes), lim = scale ? (~0ull >> 2) / (u64)scale : ~0ull;        // (sizes are untrusted: the product saturates)
+        deadline = __builtin_amdgcn_s_memrealtime() + (b < lim ? b : lim) * (u64)scale; tick = 0; fired = false;
     }
     __device__ __forceinline__ bool expired()
     {
