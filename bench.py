@@ -14,8 +14,10 @@ text/records/random/runs mix, frames produced by the real liblz4 with the refere
   On a box with fewer than N GPUs (the 1-GPU development box) the ranks share cuda:0 over gloo ("rehearsal": RCCL refuses two
   ranks on one device; at most 4 ranks) and the line says so in `config`.  The only communication is the barrier, the
   max-reduce of the timing and — strong scaling — the gather of the per-entry results on rank 0: entries are independent,
-  there is no data-path collective.  Default scaling: strong for c4_mixed (ONE archive, static shard by
-  bytes, zpack_amd/shard.py), weak for the others (one batch per rank).
+  there is no data-path collective.  c4_mixed is ONE archive sharded statically by bytes (zpack_amd/shard.py), 125 000
+  entries per GPU = BASELINE.json configs[3]'s 1 000 000 at --gpus 8; every rank generates, holds and uploads ONLY its slice
+  (--entries N or --scaling strong fix the archive's total instead).  c5_zstd1_1m is one archive of 12 500 x N source files, rank r
+  compresses files [r n, (r + 1) n) and the archive offsets come from a host scan of the per-rank totals.  C2 / C3: one batch per rank.
 
 Prints ONE JSON line (rank 0).  `value` = bytes of all ranks / max-over-ranks wall time of the K timed steps (barrier +
 synchronize on both sides).  `roofline` is for the dominant kernel(s), timed with HIP events on the launch stream inside the last
@@ -229,8 +231,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--skip-hash", action="store_true", help="diagnostic only: status ignores the XXH3 verdict (the line says so)")
     args = ap.parse_args()
+    # c4_mixed (BASELINE.json configs[3]) is ONE archive sharded statically over the ranks: 125 000 entries per GPU, i.e. the config's
+    # 1 000 000 entries at --gpus 8 (per-GPU work fixed: "weak"); --entries N or --scaling strong fix the archive's TOTAL instead
+    one_archive = args.workload == "c4_mixed" or args.scaling == "strong"
+    fixed_total = args.scaling == "strong" or (args.workload == "c4_mixed" and args.entries > 0)
     if args.scaling is None:
-        args.scaling = "strong" if args.workload == "c4_mixed" else "weak"
+        args.scaling = "strong" if (args.workload == "c4_mixed" and args.entries > 0) else "weak"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])              # nothing above has touched torch or HIP
     if args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
@@ -241,7 +247,7 @@ def main():
     import torch
     import zpack_amd
     from benchdata import datagen as dg
-    from zpack_amd.shard import shard_ranges, gather_results
+    from zpack_amd.shard import shard_ranges, gather_results, archive_bases, gather_segment_totals
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -268,7 +274,8 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.entries:
         w["n"] = args.entries
-    strong = args.scaling == "strong" and w["kind"] == "decode"
+    one_archive = one_archive and w["kind"] == "decode"
+    strong = one_archive and fixed_total
     ncores = len(os.sched_getaffinity(0))
     gen_threads = max(1, ncores // max(1, world))
     codec = zpack_amd.Codec(local_rank)
@@ -336,23 +343,26 @@ def main():
     out = None
     parity = True
     if w["kind"] == "decode":
-        # ---- synthetic archive.  weak: every rank its own batch; strong: the SAME archive everywhere, one byte-balanced slice per rank ----
+        # ---- synthetic archive.  One batch per rank (weak scaling of C2 / C3), or ONE archive (c4_mixed, --scaling strong) of which
+        # every rank generates, holds and uploads ONLY ITS SLICE: the entries' sizes are a function of the seed and the index, so every
+        # rank derives the same byte-balanced contiguous ranges (zpack_amd/shard.py) without building anything, then builds entries
+        # [lo, hi) alone ("GPU g gets descriptors + its slice of the packed stream in its own HBM") ----
         t0 = time.time()
-        seed = w["seed"] + (0 if strong else 1000 * rank)
-        batch = dg.Batch(w["n"], w["lo"], w["hi"], method=w["method"], level=w["level"], seed=seed, mix=args.mix, threads=gen_threads)
-        t_gen = time.time() - t0
         flags = zpack_amd.DF_SKIP_HASH if args.skip_hash else 0
-        if strong:
-            lo, hi = shard_ranges(batch.comp_sizes, batch.uncomp_sizes, world)[rank]
+        if one_archive:
+            n_total = w["n"] if fixed_total else w["n"] * world
+            us_all = dg.sizes(n_total, w["lo"], w["hi"], w["seed"])
+            # (compressed sizes are not known before compressing: the balance is by uncompressed bytes — the ratio of a slice of a
+            # few thousand seeded entries is the corpus mean)
+            lo, hi = shard_ranges(np.zeros(n_total, dtype=np.uint64), us_all, world)[rank]
+            batch = dg.Batch(hi - lo, w["lo"], w["hi"], method=w["method"], level=w["level"], seed=w["seed"], mix=args.mix, threads=gen_threads, first=lo)
         else:
-            lo, hi = 0, batch.n
-
-        class _Slice:                                   # the rank's contiguous range of the CDR order
-            n = hi - lo
-            offsets, comp_sizes, uncomp_sizes = batch.offsets[lo:hi], batch.comp_sizes[lo:hi], batch.uncomp_sizes[lo:hi]
-            hashes, methods = batch.hashes[lo:hi], batch.methods[lo:hi]
-        desc, dst_bytes = zpack_amd.decode_descs_from_batch(_Slice, flags=flags)
-        n = hi - lo
+            n_total = w["n"] * world
+            lo, hi = 0, w["n"]
+            batch = dg.Batch(w["n"], w["lo"], w["hi"], method=w["method"], level=w["level"], seed=w["seed"] + 1000 * rank, mix=args.mix, threads=gen_threads)
+        t_gen = time.time() - t0
+        desc, dst_bytes = zpack_amd.decode_descs_from_batch(batch, flags=flags)
+        n = batch.n
         src = torch.from_numpy(batch.archive).to(dev)
         dst = torch.empty(max(dst_bytes, 1), dtype=torch.uint8, device=dev)
         ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
@@ -372,22 +382,24 @@ def main():
         if dstats.get("lz4_two_stage_taken"):                           # k_lz4_parse inside the K_LZ4 bracket (two-stage path only)
             lz4_parse_ms = codec.kernel_ms(zpack_amd.K_LZ4_PARSE)
         codec.set_profiling(False)
-        my_uncomp = float(_Slice.uncomp_sizes.sum()) if n else 0.0
-        my_comp = float(_Slice.comp_sizes.sum()) if n else 0.0
-        total_uncomp, total_comp = allsum([my_uncomp, my_comp])
+        my_uncomp = float(batch.uncomp_sizes.sum()) if n else 0.0
+        my_comp = float(batch.comp_sizes.sum()) if n else 0.0
+        total_uncomp, total_comp, image_bytes_all = allsum([my_uncomp, my_comp, float(len(batch.archive))])
 
         # ---- parity gate: every status, every XXH3, sizes, and the bytes of a sample against the oracle ----
         res_local = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)[:n]
-        if strong and world > 1:
-            res = gather_results(res_local, lo, hi, batch.n, rank, world, dist)      # rank 0: the whole archive's results, CDR order
-            ref_hashes, ref_sizes = batch.hashes, batch.uncomp_sizes
-        else:
-            res, ref_hashes, ref_sizes = res_local, _Slice.hashes, _Slice.uncomp_sizes
-        bad, hash_ok, size_ok = 0, True, True
-        if res is not None:
-            bad = int((res["status"] != 0).sum())
-            hash_ok = bool(np.array_equal(res["hash"], ref_hashes))
-            size_ok = bool(np.array_equal(res["produced"], ref_sizes))
+        # every rank judges its own slice against what ITS generator recorded; one archive: rank 0 also holds the whole archive's
+        # results and reference hashes, concatenated in CDR order (the only thing that ever crosses ranks: 24 + 8 bytes per entry)
+        bad = int((res_local["status"] != 0).sum())
+        hash_ok = bool(np.array_equal(res_local["hash"], batch.hashes))
+        size_ok = bool(np.array_equal(res_local["produced"], batch.uncomp_sizes))
+        gathered_ok = None
+        if one_archive and world > 1:
+            res_all = gather_results(res_local, lo, hi, n_total, rank, world, dist)
+            ref_all = gather_results(np.ascontiguousarray(batch.hashes), lo, hi, n_total, rank, world, dist)
+            if rank == 0:
+                gathered_ok = bool((res_all["status"] == 0).all() and np.array_equal(res_all["hash"], ref_all) and
+                                   np.array_equal(res_all["produced"], us_all))
         bytes_ok = True
         try:
             from tests._libs import oracle
@@ -404,7 +416,7 @@ def main():
                     bytes_ok = False
         except Exception as ex:                                   # the checker is optional at run time, the hash gate is not
             bytes_ok = "oracle unavailable: %s" % ex
-        parity = bad == 0 and hash_ok and size_ok and bytes_ok is True
+        parity = bad == 0 and hash_ok and size_ok and bytes_ok is True and gathered_ok is not False
         parity = allsum([0.0 if parity else 1.0])[0] == 0.0
         if not parity:
             print("PARITY FAILURE rank %d: bad_status=%d hash_ok=%s size_ok=%s bytes_ok=%s" % (rank, bad, hash_ok, size_ok, bytes_ok),
@@ -428,18 +440,20 @@ def main():
                 "value": total_uncomp * args.steps / wall / 2**30, "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-                "config": {"workload": args.workload, "entries_per_gpu": n, "entries_total": batch.n if strong else n * world,
+                "config": {"workload": args.workload, "entries_per_gpu": n, "entries_total": n_total,
+                           "archive_image_bytes_this_rank": int(len(batch.archive)), "archive_image_bytes_all_ranks": int(image_bytes_all),
                            "entry_bytes": [w["lo"], w["hi"]],
                            "method": {0: "none", 1: "zstd", 2: "lz4", -1: "lz4+zstd coin"}[w["method"]], "level": w["level"],
                            "class_mix": "70/20/5/5 text/records/random/runs" if args.mix < 0 else ["text", "records", "random", "runs"][args.mix],
                            "comp_ratio": total_comp / max(total_uncomp, 1.0),
-                           "parallelism": ("one archive, static shard by bytes (zpack_amd/shard.py), results gathered on rank 0" if strong
+                           "parallelism": ("ONE archive of entries_total entries, static contiguous shard by bytes (zpack_amd/shard.py): every rank generates, "
+                                            "holds and uploads only its slice; results gathered on rank 0" if one_archive
                                            else "one batch per rank") + ", no data-path collective"
                                           + ("; REHEARSAL: all %d ranks share cuda:0 over gloo (fewer GPUs than ranks on this box)" % world if rehearsal else ""),
                            "rehearsal_one_card": rehearsal,
                            "frames_by": "liblz4/libzstd of the image, reference writer call sequence", "gen_seconds": round(t_gen, 1)},
                 "parity": {"all_status_ok": bad == 0, "xxh3_equal_real_xxhash": hash_ok, "sizes_equal": size_ok,
-                           "bytes_equal_oracle_sample": bytes_ok, "all_ranks": parity},
+                           "bytes_equal_oracle_sample": bytes_ok, "gathered_whole_archive": gathered_ok, "all_ranks": parity},
                 "event_ms_per_step": ev_ms / args.steps,
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "copy_ceiling_gbs": ceiling, "frac_of_copy_ceiling": (achieved / ceiling) if ceiling else None,
@@ -461,11 +475,14 @@ def main():
         # ---- C5: the write path.  Sources resident in HBM; timed = encode batch + size scan + compaction (lib/zpack_write.c:280-343) ----
         n, size, method, level = w["n"], w["lo"], w["method"], w["level"]
         t0 = time.time()
-        rng = np.random.default_rng(w["seed"] + 1000 * rank)
-        classes = rng.choice(4, size=n, p=[0.70, 0.20, 0.05, 0.05]) if args.mix < 0 else np.full(n, args.mix)
+        # ONE archive of n x world source files (BASELINE.json configs[4]: 100 000 x 1 MiB at 8 GPUs); rank r owns files [r n, (r + 1) n):
+        # class and bytes are functions of the seed and the GLOBAL index, every rank builds only its own
+        first = rank * n
+        classes = (np.random.default_rng(w["seed"]).choice(4, size=n * world, p=[0.70, 0.20, 0.05, 0.05])[first:first + n]
+                   if args.mix < 0 else np.full(n, args.mix))
         plain = np.empty(n * size, dtype=np.uint8)
         for i in range(n):
-            plain[i * size:(i + 1) * size] = dg.fill(int(classes[i]), w["seed"] + 1000 * rank, i, size)
+            plain[i * size:(i + 1) * size] = dg.fill(int(classes[i]), w["seed"], first + i, size)
         t_gen = time.time() - t0
         bound = codec.compress_bound(method, size)
         slot = (bound + 255) & ~255
@@ -517,7 +534,23 @@ def main():
                     orc_ok = False
         except Exception as ex:
             orc_ok = "oracle unavailable: %s" % ex
-        parity = ok_status and rt_ok and hash_ok and orc_ok is True
+        # ---- the archive's offsets across ranks: rank r's packed segment starts where the segments of ranks < r end (ONE host scan of
+        # `world` totals, zpack_amd/shard.py); rank 0 gathers the entry table (offset, comp_size: 16 bytes per entry) and checks the
+        # chain lib/zpack_write.c:338 builds serially: first payload at 10, every payload where its predecessor ends ----
+        totals = gather_segment_totals(total_c, rank, world, dist)
+        bases, data_end = archive_bases(totals)
+        arch_off = (ho[:-1] + bases[rank]).astype(np.uint64)
+        chain_ok = True
+        if world > 1:
+            tab = np.zeros(n, dtype=np.dtype([("offset", "<u8"), ("comp_size", "<u8")]))
+            tab["offset"] = arch_off; tab["comp_size"] = res["comp_size"]
+            tab_all = gather_results(tab, first, first + n, n * world, rank, world, dist)
+            if rank == 0:
+                chain_ok = bool(tab_all["offset"][0] == 10 and np.array_equal(tab_all["offset"][1:], tab_all["offset"][:-1] + tab_all["comp_size"][:-1])
+                                and int(tab_all["offset"][-1] + tab_all["comp_size"][-1]) == data_end)
+        else:
+            chain_ok = bool(arch_off[0] == 10 and np.array_equal(arch_off[1:], arch_off[:-1] + res["comp_size"][:-1].astype(np.uint64)))
+        parity = ok_status and rt_ok and hash_ok and orc_ok is True and chain_ok
         parity = allsum([0.0 if parity else 1.0])[0] == 0.0
         total_src, total_comp = allsum([float(n) * size, float(total_c)])
         k_ms = float(stage_ms[0])
@@ -534,15 +567,17 @@ def main():
                 "value": total_src * args.steps / wall / 2**30, "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-                "config": {"workload": args.workload, "entries_per_gpu": n, "entry_bytes": [size, size], "method": "zstd" if method == 1 else "lz4",
+                "config": {"workload": args.workload, "entries_per_gpu": n, "entries_total": n * world, "archive_data_section_bytes": data_end - 10,
+                           "entry_bytes": [size, size], "method": "zstd" if method == 1 else "lz4",
                            "level": level, "class_mix": "70/20/5/5 text/records/random/runs" if args.mix < 0 else ["text", "records", "random", "runs"][args.mix],
                            "comp_ratio": total_comp / total_src, "reference_ratio": (cpu or {}).get("ratio"),
                            "timed": "zpk_codec_encode_batch_device + zpk_codec_pack_batch_device (size scan + compaction = write_offset += comp_size)",
-                           "parallelism": "one batch per rank, no data-path collective"
+                           "parallelism": "ONE archive of entries_total source files, rank r compresses and compacts files [r n, (r + 1) n); archive offsets from a "
+                                          "host scan of the per-rank segment totals (zpack_amd/shard.py); no data-path collective"
                                           + ("; REHEARSAL: all %d ranks share cuda:0 over gloo" % world if rehearsal else ""),
                            "rehearsal_one_card": rehearsal, "gen_seconds": round(t_gen, 1)},
                 "parity": {"all_status_ok": ok_status, "gpu_decoder_round_trip_bytes_and_xxh3": rt_ok, "xxh3_equal_real_xxhash_sample": hash_ok,
-                           "oracle_decodes_sample": orc_ok, "all_ranks": parity},
+                           "oracle_decodes_sample": orc_ok, "archive_offset_chain_across_ranks": chain_ok, "all_ranks": parity},
                 "event_ms_per_step": ev_ms / args.steps,
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "copy_ceiling_gbs": ceiling, "frac_of_copy_ceiling": (achieved / ceiling) if ceiling else None,

@@ -173,6 +173,7 @@ typedef struct {
     uint64_t size_lo, size_hi;
     uint8_t* arena; uint64_t arena_cap, arena_used;
     uint64_t* local_off;
+    uint64_t first;                 /* global index of the slice's entry 0: seeds, sizes and classes are functions of the GLOBAL index */
     int error;
 } worker_t;
 
@@ -211,10 +212,11 @@ static void* worker(void* arg)
     LZ4F_createCompressionContext(&lc, LZ4F_VERSION);
     if (!plain || !zc || !lc) { w->error = 1; return NULL; }
     for (uint64_t i = w->lo; i < w->hi; i++) {
-        uint64_t n = entry_size(w->seed, i, w->size_lo, w->size_hi);
-        int cls = entry_class(w->seed, i, w->mix);
-        int method = entry_method(w->seed, i, w->method);
-        zpkgen_fill(cls, w->seed, i, plain, n);
+        const uint64_t gi = w->first + i;
+        uint64_t n = entry_size(w->seed, gi, w->size_lo, w->size_hi);
+        int cls = entry_class(w->seed, gi, w->mix);
+        int method = entry_method(w->seed, gi, w->method);
+        zpkgen_fill(cls, w->seed, gi, plain, n);
         size_t bound = method == 1 ? ZSTD_COMPRESSBOUND(n) : (method == 2 ? LZ4F_compressBound(n, NULL) : n);
         if (w->arena_used + bound + 64 > w->arena_cap) {
             uint64_t nc = (w->arena_cap + bound + 64) * 3 / 2;
@@ -271,8 +273,25 @@ void zpkgen_free(zpkgen_batch* b)
  * seeded 50/50 lz4/zstd coin; level = compression level handed to the library; mix = class 0..3 or
  * -1 for 70/20/5/5 text/records/random/runs; threads = worker threads.
  */
+zpkgen_batch* zpkgen_make_range(uint64_t first, uint64_t n, uint64_t size_lo, uint64_t size_hi, int method, int level,
+                                uint64_t seed, int mix, int threads);
 zpkgen_batch* zpkgen_make(uint64_t n, uint64_t size_lo, uint64_t size_hi, int method, int level,
                           uint64_t seed, int mix, int threads)
+{
+    return zpkgen_make_range(0, n, size_lo, size_hi, method, level, seed, mix, threads);
+}
+
+/* uncompressed sizes of entries [0, n) of the archive (seed, size range): what a rank needs to pick its byte-balanced slice
+ * WITHOUT building anything (sizes are a function of the seed and the global index) */
+void zpkgen_sizes(uint64_t n, uint64_t size_lo, uint64_t size_hi, uint64_t seed, uint64_t* out)
+{
+    for (uint64_t i = 0; i < n; i++) out[i] = entry_size(seed, i, size_lo, size_hi);
+}
+
+/* Entries [first, first + n) of that archive as a self-contained .zpk image (its own header, data section and CDR; offsets relative to
+ * THIS image): the slice one rank of a static shard holds.  Entry k of the slice is entry first + k of the whole archive, byte for byte. */
+zpkgen_batch* zpkgen_make_range(uint64_t first, uint64_t n, uint64_t size_lo, uint64_t size_hi, int method, int level,
+                                uint64_t seed, int mix, int threads)
 {
     pthread_once(&g_once, build_dictionary);
     zpkgen_batch* b = (zpkgen_batch*)calloc(1, sizeof(*b));
@@ -289,7 +308,7 @@ zpkgen_batch* zpkgen_make(uint64_t n, uint64_t size_lo, uint64_t size_hi, int me
     for (int t = 0; t < threads; t++) {
         worker_t* w = &ws[t];
         w->b = b; w->lo = n * (uint64_t)t / (uint64_t)threads; w->hi = n * (uint64_t)(t + 1) / (uint64_t)threads;
-        w->seed = seed; w->method = method; w->level = level; w->mix = mix;
+        w->seed = seed; w->method = method; w->level = level; w->mix = mix; w->first = first;
         w->size_lo = size_lo; w->size_hi = size_hi;
         w->arena_cap = (w->hi - w->lo) * (size_lo + size_hi) / 4 + (1u << 20);
         w->arena = (uint8_t*)malloc(w->arena_cap);
@@ -324,7 +343,7 @@ zpkgen_batch* zpkgen_make(uint64_t n, uint64_t size_lo, uint64_t size_hi, int me
     c += 20;
     for (uint64_t i = 0; i < n; i++) {
         char name[16];
-        snprintf(name, sizeof(name), "e%07llu", (unsigned long long)(i % 10000000ULL));
+        snprintf(name, sizeof(name), "e%07llu", (unsigned long long)((first + i) % 10000000ULL));
         wr16(c, (uint16_t)name_len); memcpy(c + 2, name, name_len); c += 2 + name_len;
         wr64(c, b->offsets[i]); wr64(c + 8, b->comp_sizes[i]); wr64(c + 16, b->uncomp_sizes[i]);
         wr64(c + 24, b->hashes[i]); c[32] = b->methods[i]; c += 33;

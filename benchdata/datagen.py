@@ -31,6 +31,9 @@ def lib():
         L = C.CDLL(SO)
         L.zpkgen_make.restype = C.POINTER(_Batch)
         L.zpkgen_make.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
+        L.zpkgen_make_range.restype = C.POINTER(_Batch)
+        L.zpkgen_make_range.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
+        L.zpkgen_sizes.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.zpkgen_free.argtypes = [C.POINTER(_Batch)]
         L.zpkgen_fill.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
         L.zpkgen_compress.restype = C.c_size_t
@@ -44,14 +47,17 @@ def lib():
 
 
 class Batch:
-    """A complete in-memory .zpk plus its entry table as numpy arrays (views into C memory)."""
+    """A complete in-memory .zpk plus its entry table as numpy arrays (views into C memory).
+    first > 0: the SLICE [first, first + n) of the archive with that seed as a self-contained image (one rank's share of a static
+    shard): entry k here is entry first + k of the whole archive, byte for byte; offsets are relative to this image."""
 
-    def __init__(self, n, size_lo, size_hi=None, method=LZ4, level=0, seed=1, mix=MIX, threads=None):
+    def __init__(self, n, size_lo, size_hi=None, method=LZ4, level=0, seed=1, mix=MIX, threads=None, first=0):
         if size_hi is None:
             size_hi = size_lo
         if threads is None:
             threads = max(1, len(os.sched_getaffinity(0)))
-        self._p = lib().zpkgen_make(n, size_lo, size_hi, method, level, seed, mix, threads)
+        self.first = first
+        self._p = lib().zpkgen_make_range(first, n, size_lo, size_hi, method, level, seed, mix, threads)
         b = self._p.contents
         if b.error:
             raise RuntimeError("zpkgen_make failed: %d" % b.error)
@@ -71,7 +77,7 @@ class Batch:
     def plaintext(self, i):
         n = int(self.uncomp_sizes[i])
         out = np.empty(max(n, 1), dtype=np.uint8)
-        lib().zpkgen_fill(int(self.classes[i]), self.seed, i, out.ctypes.data, n)
+        lib().zpkgen_fill(int(self.classes[i]), self.seed, self.first + i, out.ctypes.data, n)
         return out[:n]
 
     def close(self):
@@ -84,6 +90,13 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+def sizes(n, size_lo, size_hi, seed):
+    """uncompressed sizes of entries [0, n) of the archive with that seed — without building it"""
+    out = np.zeros(max(n, 1), dtype=np.uint64)
+    lib().zpkgen_sizes(n, size_lo, size_hi, seed, out.ctypes.data)
+    return out[:n]
 
 
 def fill(cls, seed, index, n):

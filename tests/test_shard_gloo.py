@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from zpack_amd.shard import shard_ranges, gather_results
+from zpack_amd.shard import shard_ranges, gather_results, archive_bases, gather_segment_totals
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -35,9 +35,16 @@ def _worker(rank, world, port, q, use_gpu=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from benchdata import datagen as dg
-    b = dg.Batch(48, 2000, 60000, method=dg.COIN, level=3, seed=9, threads=2)             # the same archive on every rank
-    lo, hi = shard_ranges(b.comp_sizes, b.uncomp_sizes, world)[rank]
+    # ONE archive (seed 9, 48 entries); every rank derives the byte-balanced ranges from the entries' sizes alone and BUILDS ONLY ITS
+    # SLICE ("GPU g gets descriptors + its slice of the packed stream") — as bench.py does for c4_mixed
+    n_total = 48
+    us_all = dg.sizes(n_total, 2000, 60000, 9)
+    lo, hi = shard_ranges(np.zeros(n_total, dtype=np.uint64), us_all, world)[rank]
+    b = dg.Batch(hi - lo, 2000, 60000, method=dg.COIN, level=3, seed=9, threads=2, first=lo)
+    whole = dg.Batch(n_total, 2000, 60000, method=dg.COIN, level=3, seed=9, threads=2) if rank == 0 else None      # (rank 0 only, as the checker's reference)
     local = np.zeros(hi - lo, dtype=np.dtype([("status", "<i4"), ("hash", "<u8")]))
+    lo_g, hi_g = lo, hi
+    lo, hi = 0, b.n                                                                         # indices into the slice
     if use_gpu:
         # the PRODUCT: this rank's slice through zpk_codec_decode_batch_host of its own codec context (both ranks share the one
         # card of the test box; on a node every rank has its own)
@@ -59,11 +66,13 @@ def _worker(rank, world, port, q, use_gpu=False):
             rc, out, got, h = o.entry_decode(arc, int(b.offsets[i]), int(b.comp_sizes[i]), int(b.uncomp_sizes[i]), int(b.hashes[i]),
                                              int(b.methods[i]), int(b.uncomp_sizes[i]))
             local[k] = (rc, h)
-    allr = gather_results(local, lo, hi, b.n, rank, world, dist)
-    t = torch.tensor([float(hi - lo)])
+    allr = gather_results(local, lo_g, hi_g, n_total, rank, world, dist)
+    t = torch.tensor([float(hi - lo), float(len(b.archive))])
     dist.all_reduce(t)                                                                    # bookkeeping only, as bench.py does
     if rank == 0:
-        q.put((bool((allr["status"] == 0).all()), bool(np.array_equal(allr["hash"], b.hashes)), int(t.item()), b.n))
+        # the slices together hold the data section once: each rank's image is its share of the whole archive, not a copy of it
+        slice_share_ok = len(b.archive) < 0.75 * len(whole.archive) and t[1].item() < 1.25 * len(whole.archive)
+        q.put((bool((allr["status"] == 0).all()) and slice_share_ok, bool(np.array_equal(allr["hash"], whole.hashes)), int(t[0].item()), n_total))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -105,6 +114,64 @@ def test_bench_gpus2_spawns_its_own_ranks():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity"]["all_ranks"] is True
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity"]["all_ranks"] is True and d["parity"]["gathered_whole_archive"] is True
     assert d["config"]["entries_total"] == 3000 and 0 < d["config"]["entries_per_gpu"] < 3000
+    # every rank generated and uploaded ITS SLICE: rank 0's image is about half of what the two images hold together
+    assert 0.3 < d["config"]["archive_image_bytes_this_rank"] / d["config"]["archive_image_bytes_all_ranks"] < 0.7
     assert len(d["roofline"]["stage_ms"]) == 3 and d["roofline"]["stage_names"][0] == "k_lz4_wave"
+
+
+def _write_worker(rank, world, port, q):
+    """the write path over two ranks (BASELINE.json configs[4] in miniature): rank r compresses source files [r n, (r + 1) n) of ONE archive,
+    packs them into its segment; the archive offsets come from a host scan of the per-rank totals; rank 0 concatenates the segments
+    into one .zpk and every entry of it decodes (the checker) to its source."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from benchdata import datagen as dg
+    from tests import zpk
+    from tests._libs import oracle
+    n, size = 9, 30000
+    first = rank * n
+    frames, plains = [], []
+    for i in range(n):
+        plain = dg.fill((first + i) % 4, 4, first + i, size)
+        plains.append(plain)
+        frames.append(dg.compress(dg.ZSTD, 1, plain))                                     # (the CPU stands in for the encoder here: no GPU in this test)
+    seg = b"".join(frames)
+    totals = gather_segment_totals(len(seg), rank, world, dist)
+    bases, data_end = archive_bases(totals)
+    tab = np.zeros(n, dtype=np.dtype([("offset", "<u8"), ("comp_size", "<u8"), ("hash", "<u8")]))
+    tab["comp_size"] = [len(f) for f in frames]
+    tab["offset"] = bases[rank] + np.concatenate([[0], np.cumsum(tab["comp_size"])[:-1]]).astype(np.uint64)
+    tab["hash"] = [dg.xxh3(p) for p in plains]
+    tab_all = gather_results(tab, first, first + n, n * world, rank, world, dist)
+    segs = gather_results(np.frombuffer(seg, dtype=np.uint8), int(bases[rank]) - 10, int(bases[rank]) - 10 + len(seg), data_end - 10, rank, world, dist)
+    if rank == 0:
+        chain = bool(tab_all["offset"][0] == 10 and np.array_equal(tab_all["offset"][1:], tab_all["offset"][:-1] + tab_all["comp_size"][:-1])
+                     and int(tab_all["offset"][-1] + tab_all["comp_size"][-1]) == data_end)
+        arc = zpk.assemble([segs.tobytes()], [("f%d" % i, int(tab_all["offset"][i]), int(tab_all["comp_size"][i]), size, int(tab_all["hash"][i]), 1)
+                                             for i in range(n * world)])
+        o = oracle()
+        ok = True
+        for i in range(n * world):
+            rc, out, got, h = o.entry_decode(arc, int(tab_all["offset"][i]), int(tab_all["comp_size"][i]), size, int(tab_all["hash"][i]), 1, size)
+            ok = ok and rc == 0 and out == dg.fill(i % 4, 4, i, size).tobytes()
+        q.put((chain, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_write_path_archive_offsets_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_write_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    chain, ok = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert chain and ok

@@ -25,19 +25,57 @@ def shard_ranges(comp_sizes, uncomp_sizes, world):
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+def _coll_device(dist):
+    """tensor collectives run on the backend's device: the current GPU under nccl (= RCCL), the CPU under gloo"""
+    import torch
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def gather_results(local, lo, hi, n, rank, world, dist=None):
-    """Concatenate per-rank result arrays (numpy structured or plain) on rank 0; no collective on the data path."""
+    """Concatenate per-rank result arrays (numpy structured or plain) in CDR order on rank 0; no collective on the data path.
+    Tensor collectives only (all_gather of the ranges and of the byte images, padded to the longest): the same code under gloo on
+    the CPU and under RCCL on the GPUs — no pickling through object collectives."""
     if world == 1 or dist is None:
         return local
     import torch
-    sizes = [None] * world
-    dist.all_gather_object(sizes, (int(lo), int(hi)))
-    out = None
-    if rank == 0:
-        out = np.zeros(n, dtype=local.dtype)
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object(local.tobytes(), parts, dst=0)
-    if rank == 0:
-        for (l, h), b in zip(sizes, parts):
-            out[l:h] = np.frombuffer(b, dtype=local.dtype)
+    dev = _coll_device(dist)
+    mine = torch.tensor([int(lo), int(hi)], dtype=torch.int64, device=dev)
+    ranges = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(ranges, mine)
+    ranges = [(int(r[0]), int(r[1])) for r in ranges]
+    item = local.dtype.itemsize
+    longest = max(h - l for l, h in ranges) * item
+    buf = torch.zeros(max(longest, 1), dtype=torch.uint8, device=dev)
+    raw = np.frombuffer(np.ascontiguousarray(local).tobytes(), dtype=np.uint8)
+    if raw.size:
+        buf[:raw.size] = torch.from_numpy(raw.copy()).to(dev)
+    parts = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    if rank != 0:
+        return None
+    out = np.zeros(n, dtype=local.dtype)
+    for (l, h), p in zip(ranges, parts):
+        if h > l:
+            out[l:h] = np.frombuffer(p[:(h - l) * item].cpu().numpy().tobytes(), dtype=local.dtype)
     return out
+
+
+def archive_bases(segment_totals, data_start=10):
+    """Write path over several GPUs: every rank compacts its own entries into one packed segment (the per-GPU size
+    scan, zpk_codec_pack_batch_device); the segments follow each other in rank order in the archive's data section, so rank r's base
+    is data_start + the totals of the ranks before it — the serial `write_offset += comp_size` of lib/zpack_write.c:338 across
+    ranks, from ONE host scan of `world` numbers.  -> (bases[world], end of the data section)"""
+    t = np.asarray(segment_totals, dtype=np.uint64)
+    bases = np.uint64(data_start) + np.concatenate([[np.uint64(0)], np.cumsum(t)[:-1]]).astype(np.uint64)
+    return bases, int(data_start + int(t.sum()))
+
+
+def gather_segment_totals(total, rank, world, dist=None):
+    """every rank learns every rank's packed-segment length (8 bytes per rank; bookkeeping, not data)"""
+    if world == 1 or dist is None:
+        return [int(total)]
+    import torch
+    dev = _coll_device(dist)
+    out = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(out, torch.tensor([int(total)], dtype=torch.int64, device=dev))
+    return [int(x[0]) for x in out]
