@@ -210,8 +210,13 @@ int  zpk_cstream_create(zpk_codec* c, zpk_cstream** out);
 void zpk_cstream_bind(zpk_cstream* s, zpk_codec* c);
 void zpk_cstream_reset(zpk_cstream* s);
 void zpk_cstream_destroy(zpk_cstream* s);
-int  zpk_cstream_update(zpk_cstream* s, const uint8_t* in, size_t in_size);       /* collect plaintext */
-/* compress everything collected; the frame is then drained with zpk_cstream_drain */
+/* method + level of the entry about to be streamed (before its first update): from then on zpk_cstream_update compresses as the
+ * plaintext arrives — every complete 512 KiB piece becomes a frame of its own, handed out by zpk_cstream_drain — and the device
+ * holds a few MiB of plaintext at most.  Without it update only collects and zpk_cstream_finish compresses everything. */
+int  zpk_cstream_configure(zpk_cstream* s, uint32_t method, int32_t level);
+int  zpk_cstream_update(zpk_cstream* s, const uint8_t* in, size_t in_size);       /* plaintext in; may make output available */
+/* compress what is left; *comp_size = all compressed bytes of the entry (handed out already or still to drain), *hash = XXH3-64 of the
+ * whole plaintext; the remaining bytes are then drained with zpk_cstream_drain */
 int  zpk_cstream_finish(zpk_cstream* s, uint32_t method, int32_t level, uint64_t* comp_size,
                         uint64_t* uncomp_size, uint64_t* hash);
 size_t zpk_cstream_drain(zpk_cstream* s, uint8_t* out, size_t out_cap);           /* returns bytes copied */

@@ -83,36 +83,33 @@ static size_t block_max_size(unsigned bd_code)
     }
 }
 
-int orc_lz4f_decode(const uint8_t* src, size_t src_size, uint8_t* dst, size_t dst_cap, size_t* produced)
+/* one frame (or one skippable frame) at *ipp, output at *opp; E_OK = the frame is complete (LZ4F_decompress returned 0) */
+static int lz4f_one_frame(const uint8_t* src, size_t src_size, size_t* ipp, uint8_t* dst, size_t dst_cap, size_t* opp, size_t* produced)
 {
-    size_t ip = 0, op = 0;
-    *produced = 0;
-
-    /* skippable frames may precede the real one */
-    for (;;) {
-        if (src_size - ip < 4) return E_TRUNCATED;
-        uint32_t magic = rd32(src + ip);
-        if (magic >= LZ4F_SKIP_MAGIC_LO && magic <= LZ4F_SKIP_MAGIC_HI) {
-            if (src_size - ip < 8) return E_TRUNCATED;
-            uint32_t sz = rd32(src + ip + 4);
-            if (src_size - ip - 8 < sz) return E_TRUNCATED;
-            ip += 8 + (size_t)sz;
-            continue;
-        }
-        if (magic != LZ4F_MAGIC) return E_MALFORMED;
-        break;
+    size_t ip = *ipp, op = *opp;
+    /* LZ4F_decompress decodes no header before it holds minFHSize = 7 bytes: fewer is "need more input", whatever they are */
+    if (src_size - ip < 7) { *produced = op; return E_TRUNCATED; }
+    uint32_t magic = rd32(src + ip);
+    if (magic >= LZ4F_SKIP_MAGIC_LO && magic <= LZ4F_SKIP_MAGIC_HI) {
+        if (src_size - ip < 8) { *produced = op; return E_TRUNCATED; }
+        uint32_t sz = rd32(src + ip + 4);
+        if (src_size - ip - 8 < sz) { *produced = op; return E_TRUNCATED; }
+        *ipp = ip + 8 + (size_t)sz;
+        return E_OK;
     }
+    if (magic != LZ4F_MAGIC) return E_MALFORMED;
     size_t desc_start = ip + 4;
-    if (src_size - ip < 7) return E_TRUNCATED;
     unsigned flg = src[ip + 4], bd = src[ip + 5];
     unsigned version = flg >> 6;
     int block_indep = (flg >> 5) & 1, block_cksum = (flg >> 4) & 1, has_csize = (flg >> 3) & 1;
     int content_cksum = (flg >> 2) & 1, has_dict = flg & 1;
-    if (version != 1 || (flg & 2) || (bd & 0x8F)) return E_MALFORMED;
+    /* LZ4F_decodeHeader's order: FLG is validated, then the header has to be there in full, then BD and the header checksum */
+    if (version != 1 || (flg & 2)) return E_MALFORMED;
+    size_t hdr = 7 + (has_csize ? 8 : 0) + (has_dict ? 4 : 0);
+    if (src_size - ip < hdr) { *produced = op; return E_TRUNCATED; }
+    if (bd & 0x8F) return E_MALFORMED;
     size_t bmax = block_max_size((bd >> 4) & 7);
     if (!bmax) return E_MALFORMED;
-    size_t hdr = 7 + (has_csize ? 8 : 0) + (has_dict ? 4 : 0);
-    if (src_size - ip < hdr) return E_TRUNCATED;
     uint64_t content_size = 0;
     if (has_csize) content_size = (uint64_t)rd32(src + ip + 6) | ((uint64_t)rd32(src + ip + 10) << 32);
     unsigned hc = src[ip + hdr - 1];
@@ -166,6 +163,25 @@ int orc_lz4f_decode(const uint8_t* src, size_t src_size, uint8_t* dst, size_t ds
         ip += 4;
     }
     if (has_csize && content_size != (uint64_t)(op - frame_start_op)) return E_MALFORMED;
+    *ipp = ip; *opp = op;
+    return E_OK;
+}
+
+/*
+ * The caller's loop of the reference (lib/zpack_read.c:414-439): `while (avail_out > 0 && avail_in > 0) LZ4F_decompress(...)`.
+ * A frame (or skippable frame) that completes returns 0; the loop goes on with whatever input is left, so an entry may hold
+ * several frames back to back; it stops when the input or the output space is used up, and what decides the verdict is the
+ * LAST return value (0 = a frame boundary: OK; otherwise FILE_INCOMPLETE / BUFFER_TOO_SMALL).
+ */
+int orc_lz4f_decode(const uint8_t* src, size_t src_size, uint8_t* dst, size_t dst_cap, size_t* produced)
+{
+    size_t ip = 0, op = 0;
+    *produced = 0;
+    for (int first = 1; ; first = 0) {
+        if (!first && (ip == src_size || op == dst_cap)) break;
+        int r = lz4f_one_frame(src, src_size, &ip, dst, dst_cap, &op, produced);
+        if (r != E_OK) return r;
+    }
     *produced = op;
     return E_OK;
 }

@@ -298,6 +298,31 @@ def foreign_frames():
     add("zstd:skippable_between_frames", 1, _zstd_custom(recs[:1000]) + skipz + _zstd_custom(recs[1000:]), recs)
     add("zstd:skippable_only_then_frame", 1, skipz + _zstd_custom(rnd), rnd)
     add("zstd:frame_fcs_smaller_than_capacity", 1, _zstd_custom(text[:5000]), text[:5000], max_size=9000)
+
+    # round 4: several LZ4 frames in one entry.  The reference's one-shot reader calls LZ4F_decompress in a loop
+    # `while (avail_out > 0 && avail_in > 0)` (lib/zpack_read.c:414-439): a completed frame returns 0 and the loop goes on, so
+    # frames may follow each other; what is left when the loop stops decides between OK, FILE_INCOMPLETE and BUFFER_TOO_SMALL;
+    # fewer than 7 bytes are never looked at (LZ4F's minimal header size).  Also what a chunked streaming writer may emit.
+    f1, f2 = _lz4f_custom(text[:6000]), _lz4f_custom(text[6000:], level=9)
+    add("lz4f:two_concatenated_frames", 2, f1 + f2, text)
+    add("lz4f:two_concatenated_frames_loose_capacity", 2, f1 + f2, text, max_size=len(text) + 1000)
+    add("lz4f:three_frames_middle_empty", 2, f1 + _lz4f_custom(b"") + f2, text)
+    add("lz4f:skippable_between_frames", 2, _lz4f_custom(recs[:1000]) + skip + _lz4f_custom(recs[1000:]), recs)
+    add("lz4f:frame_then_skippable", 2, f1 + skip, text[:6000], max_size=7000)
+    add("lz4f:skippable_only", 2, skip, b"")
+    add("lz4f:frame_then_5_bytes_capacity_full", 2, f1 + b"\x01\x02\x03\x04\x05", text[:6000])
+    add("lz4f:frame_then_5_bytes", 2, f1 + b"\x01\x02\x03\x04\x05", text[:6000], max_size=7000)
+    add("lz4f:frame_then_7_bytes", 2, f1 + b"\x01\x02\x03\x04\x05\x06\x07", text[:6000], max_size=7000)
+    add("lz4f:frame_then_magic_only", 2, f1 + f1[:4], text[:6000], max_size=7000)
+    add("lz4f:frame_then_truncated_frame", 2, f1 + f2[:-9], text)
+    add("lz4f:frame_then_truncated_frame_loose", 2, f1 + f2[:-9], text, max_size=len(text) + 100)
+    add("lz4f:six_bytes_of_nothing", 2, b"\x01\x02\x03\x04\x05\x06", b"x" * 100)
+    add("lz4f:seven_bytes_of_nothing", 2, b"\x01\x02\x03\x04\x05\x06\x07", b"x" * 100)
+    f = bytearray(_lz4f_custom(text, content_size=1)); f[5] |= 0x01      # a reserved BD bit AND (below) a header cut short: which is judged first
+    add("lz4f:bad_bd_full_header", 2, bytes(f), text)
+    add("lz4f:bad_bd_header_cut_short", 2, bytes(f[:10]), text)
+    g = bytearray(_lz4f_custom(text, content_size=1)); g[4] |= 0x02      # the reserved FLG bit
+    add("lz4f:bad_flg_header_cut_short", 2, bytes(g[:10]), text)
     return cases
 
 

@@ -42,7 +42,9 @@ def test_bench_spawns_ranks_as_a_child_process(monkeypatch):
 
 def test_bench_default_scaling_by_workload():
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'args.scaling = "strong" if args.workload == "c4_mixed" else "weak"' in src
+    # c4_mixed is ONE archive sharded over the ranks (125 000 entries per GPU; --entries / --scaling strong fix the total instead)
+    assert 'one_archive = args.workload == "c4_mixed" or args.scaling == "strong"' in src
+    assert 'n_total = w["n"] if fixed_total else w["n"] * world' in src and "first=lo" in src       # every rank builds only its slice
     assert 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ:' in src
 
 

@@ -436,3 +436,76 @@ def test_stream_read_survives_lying_entry_sizes(Z, method, level, claimed):
     assert rc != 0, rc                              # FILE_OFFSET_INVALID (the reader's own guard) or MALLOC_FAILED — never a decode
     Z.lib.zpack_close_stream(C.byref(st))
     Z.lib.zpack_close_reader(C.byref(r))
+
+
+@pytest.mark.parametrize("method,level,size", [(METHOD_LZ4, 0, 512 << 20), (METHOD_ZSTD, 1, 512 << 20), (METHOD_ZSTD, 3, 96 << 20), (METHOD_NONE, 0, 96 << 20),
+                                               (METHOD_LZ4, 0, (4 << 20) + 1), (METHOD_ZSTD, 3, 512 << 10), (METHOD_ZSTD, 3, (512 << 10) + 1)])
+def test_stream_write_is_bounded_and_incremental(Z, tmp_path, method, level, size):
+    """lib/zpack_write.c:461-685 compresses and emits per call.  Here: a large source through zpack_write_file_stream with a 128 KiB
+    input window — compressed bytes reach the archive long before the last input byte (first output within the first MiB), the host
+    holds no copy of the entry (resident-set growth far below the source), the device holds a few MiB of it (free device memory
+    hardly moves), and the archive — an entry made of 512 KiB frames — decodes bit-exactly with the checker, with the GPU reader
+    (one-shot and streaming) and with the compiled reference where it is present.  Sizes around the piece boundary included."""
+    import torch
+    plain = dg.fill(dg.TEXT if method != METHOD_NONE else dg.RECORDS, 29, 0, size)
+    w = Writer()
+    path = str(tmp_path / "stream.zpk")
+    assert Z.lib.zpack_init_writer(C.byref(w), path.encode()) == 0
+    assert Z.lib.zpack_write_header(C.byref(w)) == 0 and Z.lib.zpack_write_data_header(C.byref(w)) == 0
+    st = Stream()
+    assert Z.lib.zpack_init_stream(C.byref(st)) == 0
+    opts = CompressOptions(method, level)
+    out_size = Z.lib.zpack_get_cstream_out_size(method)
+    out_buf = (C.c_uint8 * out_size)()
+    st.next_out = C.cast(out_buf, u8p); st.avail_out = out_size
+    Z.lib.zpack_reset_stream(C.byref(st))
+    window = 131072
+    base = plain.ctypes.data
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rss0, rss_peak, dev_peak, first_out_at = _rss_bytes(), 0, 0, None
+    pos = 0
+    while pos < size:
+        n = min(window, size - pos)
+        st.next_in = C.cast(base + pos, u8p); st.avail_in = n
+        assert Z.lib.zpack_write_file_stream(C.byref(w), C.byref(opts), C.byref(st), None) == 0
+        pos += n
+        if first_out_at is None and st.total_out > 0:
+            first_out_at = pos
+        if (pos >> 17) % 64 == 0:
+            rss_peak = max(rss_peak, _rss_bytes() - rss0)
+            dev_peak = max(dev_peak, free0 - torch.cuda.mem_get_info()[0])
+    assert st.total_in == size
+    assert Z.lib.zpack_write_file_stream_end(C.byref(w), b"big", C.byref(opts), C.byref(st), None) == 0
+    Z.lib.zpack_close_stream(C.byref(st))
+    assert Z.lib.zpack_write_cdr(C.byref(w)) == 0 and Z.lib.zpack_write_eocdr(C.byref(w)) == 0
+    Z.lib.zpack_close_writer(C.byref(w))
+    if size > (1 << 20):
+        assert first_out_at is not None and first_out_at <= (1 << 20), first_out_at       # output long before the last input byte
+    if size >= (96 << 20):
+        assert rss_peak < (64 << 20), rss_peak                                             # no host copy of the entry
+        assert dev_peak < (192 << 20), dev_peak                                            # a few MiB of plaintext + frames (+ the codec's scratch) on the device, not the entry
+    arc = open(path, "rb").read()
+    ents = zpk.parse(arc)
+    assert len(ents) == 1 and ents[0]["uncomp_size"] == size and ents[0]["hash"] == dg.xxh3(plain) and ents[0]["method"] == method
+    e = ents[0]
+    o = oracle()
+    rc, out, got, h = o.entry_decode(arc, e["offset"], e["comp_size"], size, e["hash"], method, size)
+    assert rc == 0 and np.array_equal(np.frombuffer(out, dtype=np.uint8, count=size), plain)
+    if have_ref():
+        R = ref()
+        rc, r, keep = R.open_memory(arc)
+        assert rc == 0
+        rc, out = R.read_file(r, 0, size)
+        R.close_reader(r)
+        assert rc == 0 and np.array_equal(np.frombuffer(out, dtype=np.uint8, count=size), plain), ("reference rejects the streamed entry", rc)
+    # the GPU reader: one-shot, and streamed back with a 128 KiB window
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    rc, out = Z.read_file(r, 0, size)
+    assert rc == 0 and np.array_equal(np.frombuffer(out, dtype=np.uint8, count=size), plain)
+    if size <= (96 << 20):
+        sink = np.zeros(size, dtype=np.uint8)
+        rc, _, _, got = _stream_entry(Z, r, 0, 131075, 1 << 20, sink)
+        assert rc == 0 and got == size and np.array_equal(sink, plain)
+    Z.lib.zpack_close_reader(C.byref(r))

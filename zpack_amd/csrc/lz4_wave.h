@@ -52,7 +52,7 @@ struct DecodeOut { int rc; u64 produced; };
 
 // Streaming (zpk_stream.inc): a frame decode that runs out of INPUT at a block boundary can be picked up again when more bytes have
 // arrived.  LZ4 keeps no state between blocks but the positions (the frame header is parsed again, it is a few bytes).
-struct Lz4Resume { u64 ip_off, op_off; u32 in_blocks; };
+struct Lz4Resume { u64 ip_off, op_off, frame_ip_off, frame_op_off; u32 in_blocks, nframes; };      // (zero-initialised = the start of the entry)
 
 // ---- LZ4 block decode: lane-parallel parse out of a per-wave LDS chunk, batched execution ----------
 //
@@ -477,111 +477,127 @@ __device__ inline int lz4_block_records(Lz4WaveShared& sh, Watchdog& wd, SeqStat
 
 // whole frame.  src_lo/src_hi bound what may be READ (the archive image); all values uniform.
 // RECORDS: compressed blocks are executed from the pre-parsed records behind `cur` (two-stage path) instead of being parsed here.
+//
+// An entry may hold SEVERAL frames back to back: the reference calls LZ4F_decompress in a loop `while (avail_out > 0 && avail_in > 0)`
+// (lib/zpack_read.c:414-439) — a frame or skippable frame that completes returns 0 and the loop goes on with what is left of the
+// input; it stops when the input or the output space is used up, and the LAST return value decides (0 = a frame boundary: OK;
+// otherwise FILE_INCOMPLETE / BUFFER_TOO_SMALL).  LZ4F looks at no header before it holds 7 bytes (fewer = "need more input"), then
+// checks the magic and FLG, waits for the header in full, then checks BD and the header checksum — in that order
+// (tests/golden/foreign_frames.json "lz4f:*" round-4 cases hold the reference's verdicts).
 template <bool RECORDS = false>
 __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* src, u64 src_size, const u8* src_lo, const u8* src_hi,
                                              u8* dst, u64 dst_cap, int lane, Lz4Resume* rs = nullptr, Lz2Cursor* cur = nullptr)
 {
     DecodeOut r; r.rc = D_OK; r.produced = 0;
     const u8* ip = src;
-    const u8* iend = src + src_size;
+    const u8* const iend = src + src_size;
     u8* op = dst;
-    u8* oend = dst + dst_cap;
-
-    for (;;) {      // skippable frames
-        if (iend - ip < 4) { r.rc = D_TRUNCATED; return r; }
-        u32 magic = uld32(ip);
+    u8* const oend = dst + dst_cap;
+    bool resume_in_blocks = false, first = true;
+    if (rs && (rs->in_blocks || rs->nframes)) {      // streaming: pick up at the frame the last call stopped in (or in front of)
+        ip = src + rs->frame_ip_off; op = dst + rs->frame_op_off;
+        resume_in_blocks = rs->in_blocks != 0;
+        first = rs->nframes == 0;
+    }
+    for (;; first = false) {
+        if (wd.expired()) { r.rc = D_MALFORMED; return r; }
+        if (!first && (ip == iend || op == oend)) break;               // the reference's loop condition, between frames
+        if (rs) { rs->frame_ip_off = (u64)(ip - src); rs->frame_op_off = (u64)(op - dst); if (!resume_in_blocks) rs->in_blocks = 0; }
+        if (iend - ip < 7) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
+        const u32 magic = uld32(ip);
         if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
-            if (iend - ip < 8) { r.rc = D_TRUNCATED; return r; }
-            u64 sz = uld32(ip + 4);
-            if ((u64)(iend - ip) - 8 < sz) { r.rc = D_TRUNCATED; return r; }
+            if (iend - ip < 8) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
+            const u64 sz = uld32(ip + 4);
+            if ((u64)(iend - ip) - 8 < sz) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
             ip += 8 + sz;
+            if (rs) rs->nframes++;
             continue;
         }
         if (magic != 0x184D2204u) { r.rc = D_MALFORMED; return r; }
-        break;
-    }
-    if (iend - ip < 7) { r.rc = D_TRUNCATED; return r; }
-    const u32 flg = uld8(ip + 4), bd = uld8(ip + 5);
-    const bool indep = (flg >> 5) & 1, bck = (flg >> 4) & 1, has_cs = (flg >> 3) & 1, cck = (flg >> 2) & 1, has_dict = flg & 1;
-    if ((flg >> 6) != 1 || (flg & 2) || (bd & 0x8F)) { r.rc = D_MALFORMED; return r; }
-    const u32 bcode = (bd >> 4) & 7;
-    if (bcode < 4) { r.rc = D_MALFORMED; return r; }
-    const u64 bmax = (u64)1 << (8 + 2 * bcode);            // 4:64K 5:256K 6:1M 7:4M
-    const u32 hdr = 7 + (has_cs ? 8 : 0) + (has_dict ? 4 : 0);
-    if ((u64)(iend - ip) < hdr) { r.rc = D_TRUNCATED; return r; }
-    u64 content_size = 0;
-    if (has_cs) content_size = uni64(ld64(ip + 6));
-    {
-        u32 h = 0;
-        lane0_guard();
-        if (lane == 0) h = (xxh32_serial(ip + 4, hdr - 5, 0) >> 8) & 0xFF;
-        if (uni(h) != uld8(ip + hdr - 1)) { r.rc = D_MALFORMED; return r; }
-    }
-    ip += hdr;
+        const u32 flg = uld8(ip + 4), bd = uld8(ip + 5);
+        const bool indep = (flg >> 5) & 1, bck = (flg >> 4) & 1, has_cs = (flg >> 3) & 1, cck = (flg >> 2) & 1, has_dict = flg & 1;
+        if ((flg >> 6) != 1 || (flg & 2)) { r.rc = D_MALFORMED; return r; }
+        const u32 hdr = 7 + (has_cs ? 8 : 0) + (has_dict ? 4 : 0);
+        if ((u64)(iend - ip) < hdr) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
+        if (bd & 0x8F) { r.rc = D_MALFORMED; return r; }
+        const u32 bcode = (bd >> 4) & 7;
+        if (bcode < 4) { r.rc = D_MALFORMED; return r; }
+        const u64 bmax = (u64)1 << (8 + 2 * bcode);            // 4:64K 5:256K 6:1M 7:4M
+        u64 content_size = 0;
+        if (has_cs) content_size = uni64(ld64(ip + 6));
+        {
+            u32 h = 0;
+            lane0_guard();
+            if (lane == 0) h = (xxh32_serial(ip + 4, hdr - 5, 0) >> 8) & 0xFF;
+            if (uni(h) != uld8(ip + hdr - 1)) { r.rc = D_MALFORMED; return r; }
+        }
+        ip += hdr;
 
-    u8* frame_out = op;
-    if (rs && rs->in_blocks) { ip = src + rs->ip_off; op = dst + rs->op_off; }     // resume at the block the last call stopped in front of
-    for (;;) {
-        if (wd.expired()) { r.rc = D_MALFORMED; return r; }
-        if (rs) { rs->in_blocks = 1; rs->ip_off = (u64)(ip - src); rs->op_off = (u64)(op - dst); }     // everything before this block is done
-        if (iend - ip < 4) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
-        const u32 bh = uld32(ip);
-        ip += 4;
-        if (bh == 0) break;
-        const bool raw = bh >> 31;
-        const u64 bsz = bh & 0x7FFFFFFFu;
-        if (bsz > bmax) { r.rc = D_MALFORMED; return r; }
-        if ((u64)(iend - ip) < bsz + (bck ? 4u : 0u)) {
-            if (raw && !rs) {      // what is there of a stored block still streams out before the input starves
-                u64 n = (u64)(iend - ip); if (n > bsz) n = bsz;
+        u8* const frame_out = op;
+        if (resume_in_blocks) { ip = src + rs->ip_off; op = dst + rs->op_off; resume_in_blocks = false; }     // the block the last call stopped in front of
+        for (;;) {
+            if (wd.expired()) { r.rc = D_MALFORMED; return r; }
+            if (rs) { rs->in_blocks = 1; rs->ip_off = (u64)(ip - src); rs->op_off = (u64)(op - dst); }     // everything before this block is done
+            if (iend - ip < 4) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
+            const u32 bh = uld32(ip);
+            ip += 4;
+            if (bh == 0) break;
+            const bool raw = bh >> 31;
+            const u64 bsz = bh & 0x7FFFFFFFu;
+            if (bsz > bmax) { r.rc = D_MALFORMED; return r; }
+            if ((u64)(iend - ip) < bsz + (bck ? 4u : 0u)) {
+                if (raw && !rs) {      // what is there of a stored block still streams out before the input starves
+                    u64 n = (u64)(iend - ip); if (n > bsz) n = bsz;
+                    bool full = n > (u64)(oend - op);
+                    if (full) n = (u64)(oend - op);
+                    for (u64 i = (u64)lane * 16; i < n; i += WAVE * 16) gcopy_upto16(op + i, ip + i, (u32)(n - i < 16 ? n - i : 16));
+                    op += n;
+                    if (full) { r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r; }
+                }
+                r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r;
+            }
+            if (bck) {
+                u32 h = 0;
+                lane0_guard();
+                if (lane == 0) h = xxh32_serial(ip, bsz, 0);
+                if (uni(h) != uld32(ip + bsz)) { r.rc = D_MALFORMED; return r; }
+            }
+            if (raw) {
+                u64 n = bsz;
                 bool full = n > (u64)(oend - op);
                 if (full) n = (u64)(oend - op);
                 for (u64 i = (u64)lane * 16; i < n; i += WAVE * 16) gcopy_upto16(op + i, ip + i, (u32)(n - i < 16 ? n - i : 16));
                 op += n;
                 if (full) { r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r; }
+            } else {
+                u8* hist_lo = indep ? op : frame_out;
+                if ((u64)(op - hist_lo) > 65536) hist_lo = op - 65536;
+                u8* bend = oend;
+                bool limited = false;
+                if ((u64)(oend - op) > bmax) { bend = op + bmax; limited = true; }
+                int rc;
+                if (RECORDS) rc = lz4_block_records(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane, *cur);
+                else rc = lz4_block_wave(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane);
+                if (rc == D_DST_FULL) {
+                    if (limited) { r.rc = D_MALFORMED; return r; }
+                    r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r;
+                }
+                if (rc != D_OK) { r.rc = D_MALFORMED; return r; }
             }
-            r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r;
+            wave_mem_fence();
+            ip += bsz + (bck ? 4u : 0u);
         }
-        if (bck) {
+        if (cck) {
+            if (iend - ip < 4) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
             u32 h = 0;
             lane0_guard();
-            if (lane == 0) h = xxh32_serial(ip, bsz, 0);
-            if (uni(h) != uld32(ip + bsz)) { r.rc = D_MALFORMED; return r; }
+            if (lane == 0) h = xxh32_serial(frame_out, (u64)(op - frame_out), 0);
+            if (uni(h) != uld32(ip)) { r.rc = D_MALFORMED; return r; }
+            ip += 4;
         }
-        if (raw) {
-            u64 n = bsz;
-            bool full = n > (u64)(oend - op);
-            if (full) n = (u64)(oend - op);
-            for (u64 i = (u64)lane * 16; i < n; i += WAVE * 16) gcopy_upto16(op + i, ip + i, (u32)(n - i < 16 ? n - i : 16));
-            op += n;
-            if (full) { r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r; }
-        } else {
-            u8* hist_lo = indep ? op : frame_out;
-            if ((u64)(op - hist_lo) > 65536) hist_lo = op - 65536;
-            u8* bend = oend;
-            bool limited = false;
-            if ((u64)(oend - op) > bmax) { bend = op + bmax; limited = true; }
-            int rc;
-            if (RECORDS) rc = lz4_block_records(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane, *cur);
-            else rc = lz4_block_wave(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane);
-            if (rc == D_DST_FULL) {
-                if (limited) { r.rc = D_MALFORMED; return r; }
-                r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r;
-            }
-            if (rc != D_OK) { r.rc = D_MALFORMED; return r; }
-        }
-        wave_mem_fence();
-        ip += bsz + (bck ? 4u : 0u);
+        if (has_cs && content_size != (u64)(op - frame_out)) { r.rc = D_MALFORMED; return r; }
+        if (rs) { rs->nframes++; rs->in_blocks = 0; rs->frame_ip_off = (u64)(ip - src); rs->frame_op_off = (u64)(op - dst); }
     }
-    if (cck) {
-        if (iend - ip < 4) { r.rc = D_TRUNCATED; r.produced = (u64)(op - dst); return r; }
-        u32 h = 0;
-        lane0_guard();
-        if (lane == 0) h = xxh32_serial(frame_out, (u64)(op - frame_out), 0);
-        if (uni(h) != uld32(ip)) { r.rc = D_MALFORMED; return r; }
-        ip += 4;
-    }
-    if (has_cs && content_size != (u64)(op - frame_out)) { r.rc = D_MALFORMED; return r; }
     r.produced = (u64)(op - dst);
     return r;
 }

@@ -42,6 +42,7 @@ typedef struct zi_stream_state_s {
     zpk_dstream* d;
     zpk_cstream* c;
     int          d_active, c_active;
+    zpack_u64    entry_offset;       /* streaming write: archive offset of the entry being written */
 } zi_stream_state;
 
 /* the writer's unified sink: file or growing heap buffer, at the writer's cursor */

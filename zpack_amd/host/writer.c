@@ -260,26 +260,44 @@ int zpack_write_files_from_archive(zpack_writer* writer, zpack_reader* reader, z
     return rc;
 }
 
-/* streaming write (lib/zpack_write.c:461-685): plaintext chunks are collected, the entry is compressed
- * in one device batch when it ends, then appended — the archive that results is the same container. */
+/* streaming write (lib/zpack_write.c:461-685): the plaintext goes to the device chunk by chunk and is compressed there as it comes —
+ * every call hands what has been compressed so far to the archive through the caller's output window, as the reference does with
+ * its library buffers (:541-571); the entry is a sequence of frames (zpk_stream.inc). */
+static int stream_drain(zpack_writer* writer, zpack_stream* stream, zi_stream_state* st)
+{
+    for (;;) {
+        size_t n = zpk_cstream_drain(st->c, stream->next_out, stream->avail_out);
+        if (n == 0) return ZPACK_OK;
+        int rc = zi_writer_put(writer, stream->next_out, n);
+        if (rc) return rc;
+        stream->total_out += n;
+    }
+}
+
 int zpack_write_file_stream(zpack_writer* writer, zpack_compress_options* options, zpack_stream* stream, void* cctx)
 {
     if (!stream->next_in || !stream->next_out || !stream->avail_out) return ZPACK_ERROR_STREAM_INVALID;
     const zpack_compression_method m = options->method;
     if (m != ZPACK_COMPRESSION_NONE && m != ZPACK_COMPRESSION_ZSTD && m != ZPACK_COMPRESSION_LZ4) return ZPACK_ERROR_COMP_METHOD_INVALID;
+    if (!writer->file && !writer->buffer) return ZPACK_ERROR_WRITER_NOT_OPENED;
     zi_stream_state* st = (zi_stream_state*)stream->xxh3_state;
     if (!st) return ZPACK_ERROR_STREAM_INVALID;
     zi_ctx* ctx = zi_pick_ctx(cctx, &writer->zstd_cctx);
     if (!ctx) return ZPACK_ERROR_NOT_AVAILABLE;
     if (!st->c && zpk_cstream_create(ctx->dev[0], &st->c) != ZPK_OK) return ZPACK_ERROR_MALLOC_FAILED;
     zpk_cstream_bind(st->c, ctx->dev[0]);
-    if (stream->total_in == 0) { zpk_cstream_reset(st->c); st->c_active = 1; }
+    if (stream->total_in == 0) {
+        zpk_cstream_reset(st->c); st->c_active = 1;
+        st->entry_offset = writer->write_offset;                  /* where this entry's first byte goes */
+        int rc0 = zpk_cstream_configure(st->c, (uint32_t)m, options->level);
+        if (rc0) return rc0;
+    }
     int rc = zpk_cstream_update(st->c, stream->next_in, stream->avail_in);
     if (rc) return rc;
     stream->next_in += stream->avail_in;
     stream->total_in += stream->avail_in;
     stream->avail_in = 0;
-    return ZPACK_OK;
+    return stream_drain(writer, stream, st);
 }
 
 int zpack_write_file_stream_end(zpack_writer* writer, char* filename, zpack_compress_options* options, zpack_stream* stream, void* cctx)
@@ -294,21 +312,14 @@ int zpack_write_file_stream_end(zpack_writer* writer, char* filename, zpack_comp
     if (!ctx) return ZPACK_ERROR_NOT_AVAILABLE;
     if (!st->c && zpk_cstream_create(ctx->dev[0], &st->c) != ZPK_OK) return ZPACK_ERROR_MALLOC_FAILED;   /* an empty entry: end without update */
     zpk_cstream_bind(st->c, ctx->dev[0]);
-    if (stream->total_in == 0 && !st->c_active) zpk_cstream_reset(st->c);
+    if (stream->total_in == 0 && !st->c_active) { zpk_cstream_reset(st->c); st->entry_offset = writer->write_offset; }
     uint64_t csize = 0, usize = 0, hash = 0;
     int rc = zpk_cstream_finish(st->c, (uint32_t)m, options->level, &csize, &usize, &hash);
     if (rc) return rc;
-    const zpack_u64 at = writer->write_offset;
-    /* drain through the caller's output window, as the reference does with its library buffers */
-    for (;;) {
-        size_t n = zpk_cstream_drain(st->c, stream->next_out, stream->avail_out);
-        if (n == 0) break;
-        if ((rc = zi_writer_put(writer, stream->next_out, n))) return rc;
-        stream->total_out += n;
-    }
+    if ((rc = stream_drain(writer, stream, st))) return rc;
     zpack_file_entry* e = zi_writer_push_entry(writer);
     if (!e || !(e->filename = dup_name(filename))) return ZPACK_ERROR_MALLOC_FAILED;
-    e->offset = at;
+    e->offset = st->entry_offset;
     e->comp_size = csize;
     e->uncomp_size = usize;
     e->hash = hash;
