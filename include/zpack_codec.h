@@ -190,9 +190,9 @@ int zpk_codec_timer_start(zpk_codec* c, void* stream);
 int zpk_codec_timer_stop(zpk_codec* c, void* stream, float* elapsed_ms);   /* synchronises the stop event */
 
 /* ---- streaming triple (lib/zpack_read.c:515-640, lib/zpack_write.c:461-685) ------------------
- * Chunk granularity is hostile to the GPU, so a stream AGGREGATES: compressed input is collected until
- * the entry is complete, decoded in one batch-of-one on the device, and the output is then handed out
- * in avail_out-sized pieces.  Same observable protocol as the reference (total_in/total_out/read_back). */
+ * Chunk granularity is hostile to the GPU, so a stream GATHERS small chunks on the host (256 KiB) before it steps the device:
+ * every step decodes all complete blocks the bytes so far hold (resumable) and the output is handed out in avail_out-sized
+ * pieces while more input arrives.  Same observable protocol as the reference (total_in/total_out/read_back). */
 typedef struct zpk_dstream zpk_dstream;
 int  zpk_dstream_create(zpk_codec* c, zpk_dstream** out);
 void zpk_dstream_bind(zpk_dstream* s, zpk_codec* c);     /* the codec the NEXT step decodes with (a stream may outlive codecs) */
@@ -204,6 +204,10 @@ void zpk_dstream_destroy(zpk_dstream* s);
 int  zpk_dstream_step(zpk_dstream* s, uint32_t method, uint64_t entry_comp_size, uint64_t entry_uncomp_size,
                       uint64_t entry_hash, const uint8_t* in, size_t in_size, size_t* consumed,
                       uint8_t* out, size_t out_cap, size_t* produced, int* done);
+
+/* diagnostics: device decode steps launched / calls served since the stream's last reset (small chunks are gathered on the host: at
+ * most one launch per 256 KiB of input) */
+void zpk_dstream_counters(const zpk_dstream* s, uint64_t* launches, uint64_t* calls);
 
 typedef struct zpk_cstream zpk_cstream;
 int  zpk_cstream_create(zpk_codec* c, zpk_cstream** out);

@@ -509,3 +509,44 @@ def test_stream_write_is_bounded_and_incremental(Z, tmp_path, method, level, siz
         rc, _, _, got = _stream_entry(Z, r, 0, 131075, 1 << 20, sink)
         assert rc == 0 and got == size and np.array_equal(sink, plain)
     Z.lib.zpack_close_reader(C.byref(r))
+
+
+def test_stream_read_small_windows_do_not_launch_per_call(Z):
+    """tests/read_archive.c:38-82 feeds 16-byte input windows.  The stream gathers small chunks on the host (256 KiB) and steps the
+    device once per gathered buffer (or at the entry's last byte): a 1.2 MiB LZ4 entry read through 16-byte windows is decoded in a
+    handful of launches, not in 40 000 — counters from zpk_dstream_counters."""
+    size = 3 << 20
+    plain = dg.fill(dg.TEXT, 31, 0, size)
+    frame = bytes(dg.compress(METHOD_LZ4, 0, plain))
+    arc = zpk.assemble([frame], [("small-windows", 10, len(frame), size, dg.xxh3(plain), METHOD_LZ4)])
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    st = Stream()
+    assert Z.lib.zpack_init_stream(C.byref(st)) == 0
+    Z.lib.zpack_reset_stream(C.byref(st))
+    in_buf = (C.c_uint8 * 16)(); out_buf = (C.c_uint8 * 65536)()
+    e = r.file_entries[0]
+    sink = np.zeros(size, dtype=np.uint8)
+    pos = calls = 0
+    while not (st.total_in == e.comp_size and st.total_out == e.uncomp_size and st.read_back == 0):
+        if st.read_back:
+            tail = C.string_at(C.addressof(st.next_in.contents) - st.read_back, st.read_back)
+            C.memmove(in_buf, tail, st.read_back)
+        st.next_in = C.cast(in_buf, u8p); st.avail_in = 16
+        st.next_out = C.cast(out_buf, u8p); st.avail_out = 65536
+        rc = Z.lib.zpack_read_file_stream(C.byref(r), C.byref(e), C.byref(st), None)
+        assert rc == 0, rc
+        got = 65536 - st.avail_out
+        sink[pos:pos + got] = np.frombuffer(out_buf, dtype=np.uint8, count=got); pos += got
+        calls += 1
+        assert calls < 400000
+    assert pos == size and np.array_equal(sink, plain)
+    # the stream's device-side counters: xxh3_state -> zi_stream_state { zpk_dstream* d; ... }
+    d = C.cast(st.xxh3_state, C.POINTER(C.c_void_p))[0]
+    L = zpack_amd.lib()
+    L.zpk_dstream_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    launches, served = C.c_uint64(0), C.c_uint64(0)
+    L.zpk_dstream_counters(d, C.byref(launches), C.byref(served))
+    assert served.value >= len(frame) // 16 and launches.value <= len(frame) // (256 << 10) + 2, (launches.value, served.value, len(frame))
+    Z.lib.zpack_close_stream(C.byref(st))
+    Z.lib.zpack_close_reader(C.byref(r))
