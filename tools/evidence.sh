@@ -1,11 +1,13 @@
 #!/bin/bash
-# Round-3 evidence on the GPU box, in parts (gpurun calls are limited to 20 minutes): tools/round3_evidence.sh <part> [tag]
+# The round's evidence on the GPU box, in parts (gpurun calls are limited to 20 minutes): tools/evidence.sh <part> [tag]   (tag: r04, r05 ...)
+# (the one evidence script; earlier generations are parked in tools/attic/)
 #   a: GPU tests + smoke + C2 (kernel trace, PMC passes, then the default bench line that quotes them)
 #   b: C3 (bench, trace, PMC) + C4 bench + 2-rank rehearsal
 #   c: host-pointer rates (read and write path), C5 (bench, trace at 12 500 entries, PMC), encode rate per class at levels 1 and 3
 #   d: fuzz (damaged frames, LZ4 + Zstandard)
+#   e: the LZ4 two-stage A/B of round 4 (one-kernel path / stage 2 over the output slot / stage 2 with the LDS window), stream rates
 # Everything lands under gpurun_out/<tag>/; the PMC summaries are also copied to profiles/<tag>/ ON THE BOX so that the bench lines quote them.
-part=${1:-a}; tag=${2:-r03}
+part=${1:-a}; tag=${2:-r04}
 out=gpurun_out/$tag
 mkdir -p $out profiles/$tag
 root=$PWD
@@ -31,7 +33,8 @@ b)
   pmc2 c3 c3_zstd_256k 100000 --workload c3_zstd_256k
   timeout -k 10 900 python bench.py --workload c3_zstd_256k --steps 3 --warmup 1 > $out/${tag}_c3_zstd_bench.json 2> $out/c3.err; echo "bench c3 rc=$?"; line c3_zstd
   timeout -k 10 900 python bench.py --workload c4_mixed --steps 3 --warmup 1 > $out/${tag}_c4_mixed_bench.json 2> $out/c4.err; echo "bench c4 rc=$?"; line c4_mixed
-  timeout -k 10 600 python bench.py --gpus 2 --workload c4_mixed --entries 30000 --steps 3 --warmup 1 --no-cpu > $out/${tag}_c4_strong_2rank_rehearsal.json 2> $out/strong.err; echo "2-rank rc=$?"; cut -c1-300 $out/${tag}_c4_strong_2rank_rehearsal.json ;;
+  timeout -k 10 600 python bench.py --gpus 4 --workload c4_mixed --entries 40000 --steps 3 --warmup 1 --no-cpu > $out/${tag}_c4_4rank_40000_one_card_rehearsal.json 2> $out/strong.err; echo "4-rank rc=$?"; cut -c1-300 $out/${tag}_c4_4rank_40000_one_card_rehearsal.json
+  timeout -k 10 600 python bench.py --gpus 2 --workload c5_zstd1_1m --entries 600 --steps 2 --warmup 1 --no-cpu > $out/${tag}_c5_2rank_one_card_rehearsal.json 2> $out/c5x2.err; echo "c5 2-rank rc=$?" ;;
 c)
   { python3 tools/host_rate.py 20000 2 2>&1 | tail -2; python3 tools/host_rate.py 60000 2 2>&1 | tail -1; python3 tools/host_rate.py 8000 1 2>&1 | tail -1; } | tee $out/${tag}_host_rate.txt
   { python3 tools/host_write_rate.py 4000 1048576 1 1 2>&1 | grep -v amdgpu.ids | tail -3; python3 tools/host_write_rate.py 40000 65536 2 0 2>&1 | grep -v amdgpu.ids | tail -3; } | tee $out/${tag}_host_write_rate.txt
@@ -41,4 +44,6 @@ c)
   { timeout -k 10 300 python3 tools/enc_bench.py 4000 1048576 1 2>&1 | grep -E "^(text|records|random|runs) "; timeout -k 10 300 python3 tools/enc_bench.py 2000 1048576 3 2>&1 | grep -E "^(text|records|random|runs) "; } | tee $out/${tag}_enc_classes_levels.txt ;;
 d)
   timeout -k 10 1100 python3 tools/fuzz_gpu.py 400 11 all > $out/${tag}_fuzz_all.log 2>&1; echo "fuzz rc=$?"; tail -8 $out/${tag}_fuzz_all.log ;;
+e)
+  tools/r4_ab.sh $tag skip-tests 2>&1 | tee $out/${tag}_lz4_two_stage_ab.txt ;;
 esac
