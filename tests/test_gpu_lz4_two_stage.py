@@ -93,6 +93,8 @@ def test_two_stage_corrupted_frames_same_verdict_and_bytes_as_oracle(codec2, lev
                     f = f[:int(rng.integers(1, len(f)))]
                 if k % 13 == 0:                           # a length nibble forced to 15: extension bytes out of whatever follows
                     f[int(rng.integers(11, len(f)))] |= 0xF0
+                if k % 17 == 0:                           # a second frame behind the (damaged) first: the reference's loop decodes on
+                    f = f + bytearray(dg.compress(dg.LZ4, level, plain[:1000]))       # (tools/fuzz_gpu.py found the window path stopping behind frame 1)
             frames.append(bytes(f)); sizes.append(size)
     n = len(frames)
     offs, off = [], 10
@@ -137,10 +139,13 @@ def _desc(entries, caps):
 def test_two_stage_reference_fixtures(codec2, golden_dir):
     """The reference's own LZ4 archive, the frames its writer produced (small_archives.json), its verdicts on guard / malformed cases
     and the foreign-format frames — all through the two-stage path (batches of one: a lane, a wave, the general decoder behind)."""
+    taken = 0          # entries the two-stage path itself finished (the rest went through it to the general decoder)
     wd = os.path.join(golden_dir, "ref_workdir")
     a = open(os.path.join(wd, "archive_lz4.zpk"), "rb").read()
     ents = zpk.parse(a)
     res, outs = codec2.decode_batch_host(a, _desc(ents, [350, 350]))
+    taken += codec2.decode_stats()["lz4_two_stage"]
+    assert taken == 2                                           # the reference's own two entries: regular frames
     for e, r, out in zip(ents, res, outs):
         plain = open(os.path.join(wd, e["filename"]), "rb").read()
         assert r["status"] == 0 and int(r["hash"]) == e["hash"] and int(r["produced"]) == len(plain)
@@ -151,6 +156,8 @@ def test_two_stage_reference_fixtures(codec2, golden_dir):
         if not any(e["method"] == 2 for e in ents):
             continue
         res, outs = codec2.decode_batch_host(a, _desc(ents, [e["uncomp_size"] for e in ents]))
+        st = codec2.decode_stats()
+        assert st["lz4_two_stage"] == sum(1 for e in ents if e["comp_size"] >= 11), (case["label"], st)      # every non-empty entry of the reference writer
         for e, size, r, out in zip(ents, case["sizes"], res, outs):
             plain = dg.fill(case["cls"], case["seed"], size, size).tobytes()
             assert r["status"] == 0, (case["label"], case["corpus"], size, r)
@@ -177,6 +184,10 @@ def test_two_stage_reference_fixtures(codec2, golden_dir):
         assert int(res[0]["status"]) == c["rc"], (c["label"], res[0])
         if c["rc"] == 0:
             assert dg.xxh3(outs[0][:c["uncomp_size"]]) == c["plain_xxh3"], c["label"]
+        # only a plain single frame is the two-stage path's to finish (the slot executor also takes checksummed / sized frames);
+        # several frames, skippable frames, larger blocks go on to the general decoder
+        if any(t in c["label"] for t in ("concatenated", "three_frames", "skippable_between", "skippable_then", "skippable_only", "256k", "1m_blocks")):
+            assert codec2.decode_stats()["lz4_two_stage"] == 0, c["label"]
 
 
 def test_two_stage_entry_at_the_end_of_the_image(codec2):

@@ -17,6 +17,12 @@ from tests._libs import oracle
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 codec = zpack_amd.Codec(0)
+# ZPK_FUZZ_LZ4_TWO = slot | window: every batch through the opt-in two-stage LZ4 path (stage 2 over the output slot / with the LDS window)
+if os.environ.get("ZPK_FUZZ_LZ4_TWO") in ("slot", "window"):
+    codec.set_option(zpack_amd.OPT_LZ4_TWO_STAGE_MIN, 0)
+    codec.set_option(zpack_amd.OPT_LZ4_TWO_STAGE_MAX_COMP, 4 << 20)
+    codec.set_option(zpack_amd.OPT_LZ4_EXEC_WINDOW, 1 if os.environ["ZPK_FUZZ_LZ4_TWO"] == "window" else 0)
+    print("two-stage LZ4 path:", os.environ["ZPK_FUZZ_LZ4_TWO"])
 only_lz4 = len(sys.argv) > 3 and sys.argv[3] == "lz4"
 o = oracle()
 dev = torch.device("cuda:0")
@@ -37,6 +43,8 @@ for method, level in (((dg.LZ4, 0), (dg.LZ4, 9)) if only_lz4 else ((dg.ZSTD, 3),
                     f[int(rng.integers(0, len(f)))] ^= int(rng.integers(1, 256))
                 if k % 11 == 0:
                     f = f[:int(rng.integers(1, len(f)))]
+                if k % 17 == 0 and method == dg.LZ4:              # a second frame behind the first (the reference's LZ4F loop decodes on)
+                    f = f + bytearray(dg.compress(method, level, plain[:1000]))
                 if k % 13 == 0:                                   # a burst of zeros
                     a = int(rng.integers(0, len(f))); f[a:a + 8] = bytes(min(8, len(f) - a))
             frames.append(bytes(f)); sizes.append(size)

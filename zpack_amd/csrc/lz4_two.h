@@ -377,6 +377,9 @@ __device__ inline LxResult lz4f_window_decode_wave(Lz2ExecShared& sh, Watchdog& 
         ip += bsz;
     }
     if (cur.left != 0) { R.rc = LX_E_LIST; return R; }
+    // the reference's LZ4F_decompress loop goes on with the next frame while input AND output space are left (lib/zpack_read.c:414):
+    // an entry of several frames is the general decoder's (found by tools/fuzz_gpu.py: this path used to stop behind the first frame)
+    if (ip != iend && (u64)O.wp != dst_cap) { R.rc = LX_E_FRAME; return R; }
     lx_finish(O, dst, uncomp_size, R, lane);
     R.rc = LX_OK;
     return R;

@@ -1029,11 +1029,15 @@ static int h2d_gather(zpk_codec* c, u8* d_base, u64 total, u64 n, const uint8_t*
 }
 }  // extern "C++"
 
+// the staged image is followed by ZPK_SRC_SLACK bytes of the codec's own: the kernels may READ ZPK_SRC_READ_SLACK bytes past its
+// logical end (wide loads next to an entry's last byte; the two-stage LZ4 parser fetches whole 64-byte groups) — never interpret them
+#define ZPK_SRC_SLACK 192u
+#define ZPK_SRC_READ_SLACK 128u
 static int decode_host_chunk(zpk_codec* c, const u8* image, u64 image_size, u64 lo, u64 hi, zpk_decode_desc* hd,
                              const zpk_decode_desc* desc, u64 n, u64 out_total, uint8_t* const* dst_ptrs, zpk_decode_result* results)
 {
     int rc;
-    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, hi - lo + 16)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, out_total + 16)) ||
+    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, hi - lo + ZPK_SRC_SLACK)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, out_total + 16)) ||
         (rc = grow(c, &c->d_desc, &c->desc_cap, n * sizeof(zpk_decode_desc))) ||
         (rc = grow(c, &c->d_res, &c->res_cap, n * sizeof(zpk_decode_result)))) return rc;
     hipError_t e = hipSuccess;
@@ -1042,7 +1046,7 @@ static int decode_host_chunk(zpk_codec* c, const u8* image, u64 image_size, u64 
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
     // base pointer such that base + src_offset lands in the staged range; reads are clamped to it
     const u8* base = c->d_src - lo;
-    rc = decode_launch(c, base, image_size, c->d_src, c->d_src + (hi - lo), (const zpk_decode_desc*)c->d_desc, n,
+    rc = decode_launch(c, base, image_size, c->d_src, c->d_src + (hi - lo) + ZPK_SRC_READ_SLACK, (const zpk_decode_desc*)c->d_desc, n,
                        c->d_dst, out_total, (zpk_decode_result*)c->d_res, c->stream);
     if (rc) return rc;
     e = hipMemcpyAsync(results, c->d_res, n * sizeof(zpk_decode_result), hipMemcpyDeviceToHost, c->stream);
@@ -1116,7 +1120,7 @@ static int decode_host_pipelined(zpk_codec* c, const u8* image, u64 image_size, 
     }
     if (np < 3 || span_sum > (hi - lo) + (hi - lo) / 4 + (1u << 20)) return ZPK_OK;      // entries not in archive order: the spans would be uploaded many times over
     int rc;
-    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, hi - lo + 16)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, out_total + 16)) ||
+    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, hi - lo + ZPK_SRC_SLACK)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, out_total + 16)) ||
         (rc = grow(c, &c->d_desc, &c->desc_cap, n * sizeof(zpk_decode_desc))) ||
         (rc = grow(c, &c->d_res, &c->res_cap, n * sizeof(zpk_decode_result))) || (rc = pin_ready(c))) return rc;
     if (!c->s_up && hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking) != hipSuccess) { c->s_up = nullptr; return ZPK_OK; }
@@ -1149,7 +1153,7 @@ static int decode_host_pipelined(zpk_codec* c, const u8* image, u64 image_size, 
             if (lrc == ZPK_OK && hipStreamWaitEvent(c->stream, c->pipe_ev[2 * k], 0) != hipSuccess) lrc = ZPK_E_LAUNCH;
             const HostPiece& P = pc[k];
             if (lrc == ZPK_OK)
-                lrc = decode_launch(c, base, image_size, c->d_src + (P.clo - lo), c->d_src + (P.chi - lo), (const zpk_decode_desc*)c->d_desc + P.e0,
+                lrc = decode_launch(c, base, image_size, c->d_src + (P.clo - lo), c->d_src + (P.chi - lo) + ZPK_SRC_READ_SLACK, (const zpk_decode_desc*)c->d_desc + P.e0,
                                     P.e1 - P.e0, c->d_dst, out_total, (zpk_decode_result*)c->d_res + P.e0, c->stream);
             if (lrc == ZPK_OK && hipMemcpyAsync(c->piece_counters[k], c->d_counters, N_COUNTERS * sizeof(u32), hipMemcpyDeviceToHost, c->stream) != hipSuccess) lrc = ZPK_E_LAUNCH;
             if (lrc == ZPK_OK && hipEventRecord(c->pipe_ev[2 * k + 1], c->stream) != hipSuccess) lrc = ZPK_E_LAUNCH;
