@@ -550,3 +550,47 @@ def test_stream_read_small_windows_do_not_launch_per_call(Z):
     assert served.value >= len(frame) // 16 and launches.value <= len(frame) // (256 << 10) + 2, (launches.value, served.value, len(frame))
     Z.lib.zpack_close_stream(C.byref(st))
     Z.lib.zpack_close_reader(C.byref(r))
+
+
+@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 1)])
+def test_host_write_batch_of_many_ragged_entries(method, level):
+    """zpk_codec_encode_batch_host (what zpack_write_files calls once per batch) on 15 000 entries of ragged sizes (~750 MB: the sources
+    go up through two dozen staging pieces that cut through entries anywhere, the payloads come back as one packed stream): every
+    result OK, every XXH3 that of its source, every payload decodes back (the read pipeline) to its source."""
+    codec = zpack_amd.Codec(0)
+    n = 15000
+    rng = np.random.default_rng(77)
+    sizes = rng.integers(30000, 70000, n)
+    pool = [dg.fill(int(i % 4), 77, i, 70000) for i in range(48)]
+    srcs = [np.ascontiguousarray(pool[i % 48][:int(sizes[i])]).copy() for i in range(n)]
+    bounds = [codec.compress_bound(method, int(s)) for s in sizes]
+    outs = [np.empty(b, dtype=np.uint8) for b in bounds]
+    desc = np.zeros(n, dtype=zpack_amd.ENCODE_DESC)
+    desc["size"] = sizes; desc["dst_capacity"] = bounds; desc["method"] = method; desc["level"] = level
+    res = np.zeros(n, dtype=zpack_amd.ENCODE_RESULT)
+    sp = (C.c_void_p * n)(*[a.ctypes.data for a in srcs])
+    dp = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
+    L = codec.L
+    L.zpk_codec_encode_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    assert int(sizes.sum()) > 3 * (192 << 20)
+    rc = L.zpk_codec_encode_batch_host(codec.h, sp, desc.ctypes.data, n, dp, res.ctypes.data)
+    assert rc == 0 and (res["status"] == 0).all(), (rc, L.zpk_codec_last_error(codec.h))
+    hashes = {}
+    for i in range(n):
+        key = (i % 48, int(sizes[i]))
+        if key not in hashes:
+            hashes[key] = dg.xxh3(srcs[i])
+        assert int(res["hash"][i]) == hashes[key], i
+    # every payload back through the decoder (one image, entries back to back)
+    cs = res["comp_size"].astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(cs)])
+    arc = np.empty(int(offs[-1]) + 64, dtype=np.uint8)
+    for i in range(n):
+        arc[offs[i]:offs[i + 1]] = outs[i][:cs[i]]
+    d = np.zeros(n, dtype=zpack_amd.DECODE_DESC)
+    d["src_offset"] = offs[:-1]; d["comp_size"] = cs; d["uncomp_size"] = sizes; d["expect_hash"] = res["hash"]; d["dst_capacity"] = sizes; d["method"] = method
+    r2, back = codec.decode_batch_host(arc, d)
+    assert (r2["status"] == 0).all(), r2[r2["status"] != 0][:3]
+    for i in range(0, n, 7):
+        assert np.array_equal(back[i][:int(sizes[i])], srcs[i]), i
+    codec.close()

@@ -907,13 +907,18 @@ int zpk_codec_decode_batch_device(zpk_codec* c, const uint8_t* src, uint64_t src
 #ifndef ZPK_PIN_CHUNK
 #define ZPK_PIN_CHUNK (32ull << 20)
 #endif
+// The pinned staging buffers are touched by copy engines and host threads only, never by kernels: non-coherent host memory
+// (measured, tools/micro/pinned_copy.hip: H2D 47.8 vs 40.5 GB/s, D2H 55.9 vs 47.4 GB/s against the default, coherent kind)
+#ifndef ZPK_PIN_FLAGS
+#define ZPK_PIN_FLAGS hipHostMallocNonCoherent
+#endif
 #ifndef ZPK_SCATTER_THREADS
 #define ZPK_SCATTER_THREADS 4u
 #endif
 static int pin_ready(zpk_codec* c)
 {
     for (int k = 0; k < 2; k++) {
-        if (!c->h_pin[k] && hipHostMalloc((void**)&c->h_pin[k], ZPK_PIN_CHUNK, hipHostMallocDefault) != hipSuccess) { c->h_pin[k] = nullptr; snprintf(c->err, sizeof(c->err), "pinned staging: out of memory"); return ZPK_E_NOMEM; }
+        if (!c->h_pin[k] && hipHostMalloc((void**)&c->h_pin[k], ZPK_PIN_CHUNK, ZPK_PIN_FLAGS) != hipSuccess) { c->h_pin[k] = nullptr; snprintf(c->err, sizeof(c->err), "pinned staging: out of memory"); return ZPK_E_NOMEM; }
         if (!c->pin_ev[k] && hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { c->pin_ev[k] = nullptr; return ZPK_E_LAUNCH; }
     }
     return ZPK_OK;
@@ -983,10 +988,12 @@ static int d2h_scatter(zpk_codec* c, const u8* d_base, u64 total, u64 n, uint8_t
 // while piece j is on the bus.  Entry i owns bytes [off(i), off(i) + len(i)) of the range (ascending in i); the gaps between entries
 // carry whatever the staging buffer held.  (One hipMemcpyAsync per entry out of pageable memory: 40 000 x 64 KiB took 0.5 s.)
 template <class OffFn, class LenFn>
-static int h2d_gather(zpk_codec* c, u8* d_base, u64 total, u64 n, const uint8_t* const* src_ptrs, OffFn off, LenFn len, hipError_t& e, hipStream_t st)
+static int h2d_gather(zpk_codec* c, u8* d_base, u64 total, u64 n, const uint8_t* const* src_ptrs, OffFn off, LenFn len, hipError_t& e, hipStream_t st,
+                      u8* const* pins = nullptr, hipEvent_t* evs = nullptr)
 {
-    int rc = pin_ready(c);
+    int rc = pins ? ZPK_OK : pin_ready(c);
     if (rc) return rc;
+    if (!pins) { pins = c->h_pin; evs = c->pin_ev; }
     e = hipSuccess;
     if (total == 0) return ZPK_OK;
     const u64 npieces = (total + ZPK_PIN_CHUNK - 1) / ZPK_PIN_CHUNK;
@@ -995,7 +1002,7 @@ static int h2d_gather(zpk_codec* c, u8* d_base, u64 total, u64 n, const uint8_t*
     for (u64 j = 0; j < npieces && e == hipSuccess; j++) {
         const int k = (int)(j & 1);
         const u64 p0 = j * ZPK_PIN_CHUNK, p1 = p0 + ZPK_PIN_CHUNK < total ? p0 + ZPK_PIN_CHUNK : total;
-        if (used[k]) { e = hipEventSynchronize(c->pin_ev[k]); if (e != hipSuccess) break; }      // the buffer's previous piece has left
+        if (used[k]) { e = hipEventSynchronize(evs[k]); if (e != hipSuccess) break; }      // the buffer's previous piece has left
         while (ei < n && off(ei) + len(ei) <= p0) ei++;
         u64 ej = ei;
         while (ej < n && off(ej) < p1) ej++;
@@ -1003,7 +1010,7 @@ static int h2d_gather(zpk_codec* c, u8* d_base, u64 total, u64 n, const uint8_t*
             for (u64 i = lo_i; i < hi_i; i++) {
                 const u64 o = off(i), l = len(i);
                 const u64 a = o > p0 ? o : p0, z = o + l < p1 ? o + l : p1;
-                if (z > a) memcpy(c->h_pin[k] + (a - p0), src_ptrs[i] + (a - o), z - a);
+                if (z > a) memcpy(pins[k] + (a - p0), src_ptrs[i] + (a - o), z - a);
             }
         };
         const u64 cnt = ej - ei;
@@ -1019,12 +1026,12 @@ static int h2d_gather(zpk_codec* c, u8* d_base, u64 total, u64 n, const uint8_t*
             part(ei, ei + cnt / T);
             for (unsigned t = 1; t < T; t++) { if (started[t - 1]) th[t - 1].join(); else part(ei + cnt * t / T, ei + cnt * (t + 1) / T); }
         }
-        e = hipMemcpyAsync(d_base + p0, c->h_pin[k], p1 - p0, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipEventRecord(c->pin_ev[k], st);
+        e = hipMemcpyAsync(d_base + p0, pins[k], p1 - p0, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(evs[k], st);
         used[k] = true;
     }
     // the pinned buffers serve the download next: both uploads have to be off them
-    for (int k = 0; k < 2 && e == hipSuccess; k++) if (used[k]) e = hipEventSynchronize(c->pin_ev[k]);
+    for (int k = 0; k < 2 && e == hipSuccess; k++) if (used[k]) e = hipEventSynchronize(evs[k]);
     return ZPK_OK;
 }
 }  // extern "C++"
