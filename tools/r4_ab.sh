@@ -11,8 +11,8 @@ args="--entries 100000 --steps 5 --warmup 2 --no-cpu"
 for mode in one g w; do
   unset ZPK_BENCH_LZ4_TWO ZPK_BENCH_LZ4_EXEC_WINDOW
   [ $mode = one ] && export ZPK_BENCH_LZ4_TWO=never
-  [ $mode = w ] && export ZPK_BENCH_LZ4_EXEC_WINDOW=1
-  [ $mode = g ] && export ZPK_BENCH_LZ4_EXEC_WINDOW=0
+  [ $mode = w ] && export ZPK_BENCH_LZ4_EXEC_WINDOW=1 ZPK_BENCH_LZ4_TWO=always
+  [ $mode = g ] && export ZPK_BENCH_LZ4_EXEC_WINDOW=0 ZPK_BENCH_LZ4_TWO=always
   timeout -k 10 200 python3 $root/bench.py $args > $out/bench_$mode.json 2> $out/bench_$mode.err
   python3 - <<PY
 import json
