@@ -190,6 +190,60 @@ __device__ inline void lz4_parse_lanes(Lz2ParseShared& sh, const u8* __restrict_
 
 
 // ================================================================================================================================
+// Stage 2 over the entry's OUTPUT SLOT (k_lz4_exec_g): the frames the reference writer produces and their plain variations (any block
+// count, stored blocks, linked or independent blocks), compressed blocks executed from the records by lz4_block_records (lz4_wave.h:
+// seq_exec_batch, window = the slot in memory).  Checksummed, sized or dictionary frames, skippable frames, several frames in one
+// entry and anything malformed are the general decoder's (rc != D_OK).  Its own small frame walker rather than lz4f_decode_wave's:
+// the general walker's resume / multi-frame state cost this kernel its registers (92 bytes of scratch in the batch loop: 3.5 x slower).
+__device__ inline DecodeOut lz4f_slot_decode_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* src, u64 src_size, const u8* src_hi,
+                                                  u8* dst, u64 dst_cap, int lane, Lz2Cursor& cur)
+{
+    DecodeOut r; r.rc = D_MALFORMED; r.produced = 0;
+    if (src_size < 11) return r;
+    const u8* ip = src;
+    const u8* const iend = src + src_size;
+    u8* op = dst;
+    u8* const oend = dst + dst_cap;
+    if (uld32(ip) != 0x184D2204u) return r;
+    const u32 flg = uld8(ip + 4), bd = uld8(ip + 5);
+    if ((flg != 0x40u && flg != 0x60u) || bd != 0x40u) return r;
+    {
+        u32 h = 0;
+        lane0_guard();
+        if (lane == 0) h = (xxh32_serial(ip + 4, 2, 0) >> 8) & 0xFF;
+        if (uni(h) != uld8(ip + 6)) return r;
+    }
+    const bool indep = (flg >> 5) & 1;
+    ip += 7;
+    for (;;) {
+        if (wd.expired()) return r;
+        if (iend - ip < 4) return r;
+        const u32 bh = uld32(ip);
+        ip += 4;
+        if (bh == 0) break;
+        const u64 bsz = bh & 0x7FFFFFFFu;
+        if (bsz > 65536u || (u64)(iend - ip) < bsz) return r;
+        if (bh >> 31) {
+            if (bsz > (u64)(oend - op)) return r;
+            for (u64 i = (u64)lane * 16; i < bsz; i += WAVE * 16) gcopy_upto16(op + i, ip + i, (u32)(bsz - i < 16 ? bsz - i : 16));
+            op += bsz;
+        } else {
+            u8* hist_lo = indep ? op : dst;
+            if ((u64)(op - hist_lo) > 65536) hist_lo = op - 65536;
+            u8* bend = oend;
+            if ((u64)(oend - op) > 65536u) bend = op + 65536u;
+            if (lz4_block_records(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane, cur) != D_OK) return r;
+        }
+        wave_mem_fence();
+        ip += bsz;
+    }
+    // (more frames behind this one while output space is left: the reference's loop decodes on — the general decoder's)
+    if (ip != iend && op != oend) return r;
+    r.rc = D_OK; r.produced = (u64)(op - dst);
+    return r;
+}
+
+// ================================================================================================================================
 // Stage 2 with an LDS OUTPUT WINDOW (k_lz4_exec).
 //
 // What bounds the execution of LZ4 sequences on this part is not instruction issue but LINE FETCHES (profiles/r04: the record-driven

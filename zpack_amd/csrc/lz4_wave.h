@@ -476,17 +476,14 @@ __device__ inline int lz4_block_records(Lz4WaveShared& sh, Watchdog& wd, SeqStat
 }
 
 // whole frame.  src_lo/src_hi bound what may be READ (the archive image); all values uniform.
-// RECORDS: compressed blocks are executed from the pre-parsed records behind `cur` (two-stage path) instead of being parsed here.
-//
 // An entry may hold SEVERAL frames back to back: the reference calls LZ4F_decompress in a loop `while (avail_out > 0 && avail_in > 0)`
 // (lib/zpack_read.c:414-439) — a frame or skippable frame that completes returns 0 and the loop goes on with what is left of the
 // input; it stops when the input or the output space is used up, and the LAST return value decides (0 = a frame boundary: OK;
 // otherwise FILE_INCOMPLETE / BUFFER_TOO_SMALL).  LZ4F looks at no header before it holds 7 bytes (fewer = "need more input"), then
 // checks the magic and FLG, waits for the header in full, then checks BD and the header checksum — in that order
 // (tests/golden/foreign_frames.json "lz4f:*" round-4 cases hold the reference's verdicts).
-template <bool RECORDS = false>
 __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* src, u64 src_size, const u8* src_lo, const u8* src_hi,
-                                             u8* dst, u64 dst_cap, int lane, Lz4Resume* rs = nullptr, Lz2Cursor* cur = nullptr)
+                                             u8* dst, u64 dst_cap, int lane, Lz4Resume* rs = nullptr)
 {
     DecodeOut r; r.rc = D_OK; r.produced = 0;
     const u8* ip = src;
@@ -575,9 +572,7 @@ __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, Se
                 u8* bend = oend;
                 bool limited = false;
                 if ((u64)(oend - op) > bmax) { bend = op + bmax; limited = true; }
-                int rc;
-                if (RECORDS) rc = lz4_block_records(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane, *cur);
-                else rc = lz4_block_wave(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane);
+                const int rc = lz4_block_wave(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane);
                 if (rc == D_DST_FULL) {
                     if (limited) { r.rc = D_MALFORMED; return r; }
                     r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r;

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64, 7) void k_lz4_exec_g(const u8* __restrict__ src
         SeqStats stt = {};
         Lz2Cursor cur; cur.rec = arena + rec_base; cur.left = nrec;
         cur.hash_begin(out, usz, lane);
-        const DecodeOut o = lz4f_decode_wave<true>(shw, wd, stt, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane, nullptr, &cur);
+        const DecodeOut o = lz4f_slot_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_hi, out, uni64(d.dst_capacity), lane, cur);
         if (o.rc == D_OK && cur.left == 0 && !wd.fired) {
             u64 h;
             wave_mem_fence();
