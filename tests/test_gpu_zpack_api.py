@@ -594,3 +594,72 @@ def test_host_write_batch_of_many_ragged_entries(method, level):
     for i in range(0, n, 7):
         assert np.array_equal(back[i][:int(sizes[i])], srcs[i]), i
     codec.close()
+
+
+def _stream_roundtrip(Z, tmp_path, plain, method, level, in_chunks, read_in, read_out, tag, empty_update=False):
+    """write `plain` through zpack_write_file_stream in chunks of the given sizes (cycled), read it back through
+    zpack_read_file_stream with the given windows; -> the archive bytes"""
+    w = Writer()
+    path = str(tmp_path / ("s_%s.zpk" % tag))
+    assert Z.lib.zpack_init_writer(C.byref(w), path.encode()) == 0
+    assert Z.lib.zpack_write_header(C.byref(w)) == 0 and Z.lib.zpack_write_data_header(C.byref(w)) == 0
+    st = Stream()
+    assert Z.lib.zpack_init_stream(C.byref(st)) == 0
+    opts = CompressOptions(method, level)
+    out_size = Z.lib.zpack_get_cstream_out_size(method)
+    out_buf = (C.c_uint8 * out_size)()
+    st.next_out = C.cast(out_buf, u8p); st.avail_out = out_size
+    Z.lib.zpack_reset_stream(C.byref(st))
+    size = len(plain)
+    base = plain.ctypes.data if size else 0
+    dummy = (C.c_uint8 * 1)()
+    pos = k = 0
+    while pos < size:
+        n = min(in_chunks[k % len(in_chunks)], size - pos); k += 1
+        st.next_in = C.cast(base + pos, u8p); st.avail_in = n
+        assert Z.lib.zpack_write_file_stream(C.byref(w), C.byref(opts), C.byref(st), None) == 0
+        pos += n
+    if size == 0:
+        st.next_in = C.cast(dummy, u8p); st.avail_in = 0
+        if empty_update:                                                               # an empty entry with, and without, a (0-byte) update
+            assert Z.lib.zpack_write_file_stream(C.byref(w), C.byref(opts), C.byref(st), None) == 0
+    assert Z.lib.zpack_write_file_stream_end(C.byref(w), b"e", C.byref(opts), C.byref(st), None) == 0
+    Z.lib.zpack_close_stream(C.byref(st))
+    assert Z.lib.zpack_write_cdr(C.byref(w)) == 0 and Z.lib.zpack_write_eocdr(C.byref(w)) == 0
+    Z.lib.zpack_close_writer(C.byref(w))
+    arc = open(path, "rb").read()
+    ents = zpk.parse(arc)
+    assert len(ents) == 1 and ents[0]["uncomp_size"] == size and ents[0]["hash"] == dg.xxh3(plain), (tag, ents)
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    if size:
+        sink = np.zeros(size, dtype=np.uint8)
+        rc, _, _, got = _stream_entry(Z, r, 0, read_in, read_out, sink)
+        assert rc == 0 and got == size and np.array_equal(sink, plain), (tag, rc, got)
+    rc, out = Z.read_file(r, 0, max(size, 1))
+    assert rc == 0 and np.array_equal(np.frombuffer(out, dtype=np.uint8, count=size), plain), (tag, rc)
+    Z.lib.zpack_close_reader(C.byref(r))
+    return arc, ents[0]
+
+
+def test_stream_roundtrips_random_sizes_and_windows(Z, tmp_path):
+    """Randomized: entries of 0 bytes ... 6 MiB (around the streaming writer's 512 KiB pieces, its 4 MiB steps and the reader's 256 KiB
+    gather buffer on purpose), every method, written in chunks of 1 byte ... 700 KiB (mixed within one entry) and read back through
+    windows of 16 bytes ... 1 MiB: every byte, the XXH3, and the checker's decode of the written entry."""
+    rng = np.random.default_rng(int(os.environ.get("ZPK_STREAM_FUZZ_SEED", "20261004")))
+    o = oracle()
+    edges = [0, 0, 0, 0, 1, 240, 241, (512 << 10) - 1, 512 << 10, (512 << 10) + 1, (1 << 20) + 3, (4 << 20), (4 << 20) + 1, (4 << 20) + (512 << 10) + 1]
+    for it in range(int(os.environ.get("ZPK_STREAM_FUZZ_ITERS", "30"))):               # (a longer soak: tools/evidence.sh e)
+        size = edges[it] if it < len(edges) else int(rng.integers(1, 6 << 20))
+        method, level = [(METHOD_LZ4, 0), (METHOD_ZSTD, 1), (METHOD_ZSTD, 3), (METHOD_NONE, 0), (METHOD_LZ4, 9)][it % 5]
+        plain = dg.fill(int(rng.integers(0, 4)), 99, it, size)
+        style = it % 4
+        in_chunks = ([int(rng.integers(1, 700 << 10)) for _ in range(7)] if style == 0 else [131072] if style == 1
+                     else [int(rng.integers(1, 5000)), int(rng.integers(200 << 10, 700 << 10))] if style == 2 else [512 << 10, 1, (512 << 10) - 1])
+        if size > (2 << 20) and min(in_chunks) < 64:
+            in_chunks = [c if c >= 64 else 4096 for c in in_chunks]                       # (keeps the call count of large entries in bounds)
+        read_in = [16, 1000, 131075, 1 << 20][int(rng.integers(0, 4))] if size < (1 << 20) else [131075, 1 << 20, 70000][int(rng.integers(0, 3))]
+        read_out = [64, 4096, 1 << 20][int(rng.integers(0, 3))] if size < (1 << 18) else [65536, 1 << 20][int(rng.integers(0, 2))]
+        arc, e = _stream_roundtrip(Z, tmp_path, plain, method, level, in_chunks, read_in, read_out, "r%d" % it, empty_update=bool(it & 1))
+        rc, out, got, h = o.entry_decode(arc, e["offset"], e["comp_size"], size, e["hash"], method, max(size, 1))
+        assert rc == 0 and np.array_equal(np.frombuffer(out, dtype=np.uint8, count=size), plain), (it, size, method, rc)

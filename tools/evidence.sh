@@ -46,4 +46,7 @@ d)
   timeout -k 10 1100 python3 tools/fuzz_gpu.py 400 11 all > $out/${tag}_fuzz_all.log 2>&1; echo "fuzz rc=$?"; tail -8 $out/${tag}_fuzz_all.log ;;
 e)
   tools/r4_ab.sh $tag skip-tests 2>&1 | tee $out/${tag}_lz4_two_stage_ab.txt ;;
+f)
+  # soak of the streaming write / read pair: random entry sizes, chunkings and windows (the suite runs 30 of these; here 600 more, other seed)
+  ZPK_STREAM_FUZZ_ITERS=600 ZPK_STREAM_FUZZ_SEED=7 timeout -k 10 1000 python -m pytest tests/test_gpu_zpack_api.py -x -q -m gpu -k random_sizes_and_windows > $out/${tag}_stream_soak.log 2>&1; echo "stream soak rc=$?" | tee -a $out/${tag}_stream_soak.log; tail -4 $out/${tag}_stream_soak.log ;;
 esac
