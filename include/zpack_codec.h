@@ -88,9 +88,14 @@ typedef struct zpk_encode_desc {
     uint64_t size;
     uint64_t dst_offset;       /* output slot offset inside `dst` */
     uint64_t dst_capacity;
-    uint32_t method;
+    uint32_t method;           /* ZPK_METHOD_*, optionally | ZPK_EF_PIECE */
     int32_t  level;
 } zpk_encode_desc;
+
+/* The entry is one frame of a SEQUENCE of frames that together are an archive entry (large entries of the host path, the streaming
+ * writer): an LZ4 frame then carries its content size in the header (a Zstandard frame always does), so that a reader can place the
+ * frames' outputs without decoding them — and decode them side by side; result.hash is left 0 (the entry's hash covers all frames). */
+#define ZPK_EF_PIECE 0x80000000u
 
 typedef struct zpk_encode_result {
     int32_t  status;
@@ -115,8 +120,18 @@ int         zpk_codec_device(const zpk_codec* c);
  *                                   workload the path measured slower than the one-kernel decoder (profiles/r04).
  *   ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP  ... for entries of at most `value` compressed bytes (one lane walks one entry; longer entries
  *                                   stay with the one-wave decoder).  Default 96 KiB.
- * The results are identical either way (every irregular entry is decoded by the general decoder, which alone gives verdicts). */
-enum { ZPK_OPT_LZ4_TWO_STAGE_MIN = 2, ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP = 3,
+ * The results are identical either way (every irregular entry is decoded by the general decoder, which alone gives verdicts).
+ *   ZPK_OPT_ENC_SPLIT_MIN           zpk_codec_encode_batch_host: an entry of at least `value` bytes is compressed as a SEQUENCE OF
+ *                                   FRAMES, one per 512 KiB of plaintext, all of them side by side (one wave encodes one frame: a
+ *                                   256 MiB entry is 512 waves instead of one), its XXH3 by the whole chip (per-block partial sums,
+ *                                   then one short chain).  Both readers of the reference continue with the next frame
+ *                                   (lib/zpack_read.c:380, :414-439), and the sequence fits the reference's own bound for the entry.
+ *                                   Default 2 MiB; 0 = never split.
+ *   ZPK_OPT_DEC_SPLIT_MIN           zpk_codec_decode_batch_host: an entry of at least `value` bytes that IS such a sequence (>= 2 frames
+ *                                   that tile it exactly, each stating its content size; or a stored entry) is decoded with one wave
+ *                                   per FRAME and hashed by the whole chip; any other entry, and any entry a frame of which fails,
+ *                                   is decoded by one wave as before (verdicts come from there only).  Default 2 MiB; 0 = never. */
+enum { ZPK_OPT_LZ4_TWO_STAGE_MIN = 2, ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP = 3, ZPK_OPT_ENC_SPLIT_MIN = 6, ZPK_OPT_DEC_SPLIT_MIN = 7,
        ZPK_OPT_LZ4_EXEC_WINDOW = 5 /* stage 2 of the two-stage path: 1 = output assembled in an LDS window, 0 = in the output slot */,
        ZPK_OPT_DEV_LZ4_EXEC_PAD = 4 /* measurement aid: bytes of idle LDS per stage-2 workgroup, i.e. fewer entries in flight per CU */ };
 int         zpk_codec_set_option(zpk_codec* c, int option, int value);
@@ -176,7 +191,8 @@ int zpk_codec_set_profiling(zpk_codec* c, int enabled);
 /* out[0], out[1] = LZ4 / Zstandard entries of the most recent decode batch whose first decode ran out of its time budget (a
  * contended or preempted GPU) and that were decoded again, behind the batch, with a 64 x larger one — a slow wave is not a
  * verdict; expected 0 on an idle GPU.  out[2], out[3] = LZ4 entries finished by the two-stage path / handed by it to the general
- * decoder; out[4] = 1 when the batch took the two-stage path at all */
+ * decoder; out[4] = 1 when the batch took the two-stage path at all; out[5], out[6] = entries of the most recent
+ * zpk_codec_decode_batch_host call that were decoded frame-parallel (ZPK_OPT_DEC_SPLIT_MIN) and the frames they had */
 int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16]);
 /* counters of the most recent decode batch (synchronises): out[0..2] = entries on the stored / zstd / lz4 work
  * lists, out[3] = Zstandard entries finished on pre-decoded sequences (two-stage path), out[4] = by the fused decoder,

@@ -1,0 +1,178 @@
+"""Large entries (SURVEY.md §8 a4 / a5 / a8 in depth): one wave works on one FRAME, so an entry of hundreds of MiB in one frame is one
+wave's work.  The host write path cuts entries of >= 2 MiB into 512 KiB pieces — one frame each, side by side, XXH3 by the whole chip —
+and the host read path decodes an entry that is such a sequence with one wave per frame.  Checked here: the bytes, hashes and
+verdicts are those of the one-wave paths, of the oracle and of the compiled reference (whose readers continue with the next frame:
+lib/zpack_read.c:380, :414-439)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import zpack_amd
+from benchdata import datagen as dg
+from tests._libs import oracle, have_ref, ref
+from zpack_amd import METHOD_NONE, METHOD_ZSTD, METHOD_LZ4, OPT_ENC_SPLIT_MIN, OPT_DEC_SPLIT_MIN
+
+pytestmark = pytest.mark.gpu
+M = 1 << 20
+PIECE = 512 << 10
+
+
+@pytest.fixture(scope="module")
+def codec():
+    c = zpack_amd.Codec(0)
+    yield c
+    c.close()
+
+
+def _encode(codec, plains, methods):
+    n = len(plains)
+    bounds = [codec.compress_bound(m, len(p)) for p, (m, _) in zip(plains, methods)]
+    outs = [np.zeros(max(b, 1), dtype=np.uint8) for b in bounds]
+    desc = np.zeros(n, dtype=zpack_amd.ENCODE_DESC)
+    desc["size"] = [len(p) for p in plains]; desc["dst_capacity"] = bounds
+    desc["method"] = [m for m, _ in methods]; desc["level"] = [lv for _, lv in methods]
+    res = np.zeros(n, dtype=zpack_amd.ENCODE_RESULT)
+    sp = (C.c_void_p * n)(*[p.ctypes.data for p in plains])
+    dp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    L = codec.L
+    L.zpk_codec_encode_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    rc = L.zpk_codec_encode_batch_host(codec.h, sp, desc.ctypes.data, n, dp, res.ctypes.data)
+    assert rc == 0 and (res["status"] == 0).all(), (rc, res)
+    return res, [o[:int(c)] for o, c in zip(outs, res["comp_size"])]
+
+
+def _image(payloads):
+    cs = np.array([len(p) for p in payloads], dtype=np.int64)
+    offs = np.concatenate([[10], 10 + np.cumsum(cs)])
+    arc = np.zeros(int(offs[-1]) + 64, dtype=np.uint8)
+    for i, p in enumerate(payloads):
+        arc[offs[i]:offs[i + 1]] = p
+    return arc, offs[:-1], cs
+
+
+def _descs(offs, cs, sizes, hashes, methods, flags=0):
+    d = np.zeros(len(cs), dtype=zpack_amd.DECODE_DESC)
+    d["src_offset"] = offs; d["comp_size"] = cs; d["uncomp_size"] = sizes; d["expect_hash"] = hashes
+    d["dst_capacity"] = sizes; d["method"] = [m for m, _ in methods]; d["flags"] = flags
+    return d
+
+
+CASES = [(METHOD_LZ4, 0, 2 * M), (METHOD_LZ4, 0, 3 * M + 17), (METHOD_ZSTD, 3, 2 * M + 1), (METHOD_ZSTD, 1, 7 * M - 5), (METHOD_NONE, 0, 4 * M + 3),
+         (METHOD_LZ4, 0, 2 * M - 1), (METHOD_ZSTD, 1, 300000), (METHOD_NONE, 0, 70000), (METHOD_LZ4, 9, 5 * M), (METHOD_ZSTD, 1, 33 * M + 777)]
+
+
+def test_big_entries_frame_parallel_equals_one_wave(codec):
+    """Written split, read frame-parallel; the same archive read with the split switched off; an unsplit writing of the same
+    plaintexts: every variant gives the same bytes, hashes (the real xxHash's) and produced counts, and the counters say which path ran."""
+    plains = [dg.fill(i % 4, 321, i, n) for i, (_, _, n) in enumerate(CASES)]
+    methods = [(m, lv) for m, lv, _ in CASES]
+    sizes = [n for _, _, n in CASES]
+    want = [dg.xxh3(p) for p in plains]
+    codec.set_option(OPT_ENC_SPLIT_MIN, 2 * M)
+    res, pay = _encode(codec, plains, methods)
+    assert [int(h) for h in res["hash"]] == want
+    arc, offs, cs = _image(pay)
+    d = _descs(offs, cs, sizes, res["hash"], methods)
+    nbig = sum(1 for n in sizes if n >= 2 * M)
+    nframes = sum((n + PIECE - 1) // PIECE for n in sizes if n >= 2 * M)
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    r1, out1 = codec.decode_batch_host(arc, d)
+    st = codec.decode_stats()
+    assert st["frame_parallel_entries"] == nbig and st["frame_parallel_frames"] == nframes, st
+    codec.set_option(OPT_DEC_SPLIT_MIN, 0)
+    r0, out0 = codec.decode_batch_host(arc, d)
+    st = codec.decode_stats()
+    assert st["frame_parallel_entries"] == 0
+    for r in (r0, r1):
+        assert (r["status"] == 0).all() and [int(h) for h in r["hash"]] == want and [int(x) for x in r["produced"]] == sizes
+    for i, p in enumerate(plains):
+        assert np.array_equal(out1[i], p) and np.array_equal(out0[i], p), i
+    # the checkers on the split payloads
+    o = oracle()
+    arc_b = arc.tobytes()
+    for i, p in enumerate(plains):
+        if sizes[i] > 8 * M:
+            continue
+        rc, out, got, h = o.entry_decode(arc_b, int(offs[i]), int(cs[i]), sizes[i], want[i], methods[i][0], sizes[i])
+        assert rc == 0 and out == p.tobytes(), (i, rc)
+    # unsplit writing: other bytes, same plaintext behind them; the read path finds nothing to split
+    codec.set_option(OPT_ENC_SPLIT_MIN, 0)
+    res2, pay2 = _encode(codec, plains[:5], methods[:5])
+    assert [int(h) for h in res2["hash"]] == want[:5]
+    arc2, offs2, cs2 = _image(pay2)
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    r2, out2 = codec.decode_batch_host(arc2, _descs(offs2, cs2, sizes[:5], res2["hash"], methods[:5]))
+    st = codec.decode_stats()
+    assert (r2["status"] == 0).all() and st["frame_parallel_entries"] == 1          # (only the stored entry: slices need no frames)
+    for i in range(5):
+        assert np.array_equal(out2[i], plains[i])
+    codec.set_option(OPT_ENC_SPLIT_MIN, 2 * M)
+
+
+def test_big_entry_damage_gets_the_one_wave_verdict(codec):
+    """A frame sequence with a damaged frame, a damaged frame header, a short or long comp_size, a wrong hash, a capacity below the size:
+    the frame-parallel reader gives exactly what the one-wave reader gives (status, detail, produced, hash), which is what the oracle
+    and the compiled reference say."""
+    codec.set_option(OPT_ENC_SPLIT_MIN, 2 * M)
+    o = oracle()
+    rng = np.random.default_rng(9)
+    for method, level in [(METHOD_LZ4, 0), (METHOD_ZSTD, 1), (METHOD_NONE, 0)]:
+        plain = dg.fill(dg.TEXT, 55, method, 3 * M + 4321)
+        res, pay = _encode(codec, [plain], [(method, level)])
+        good = pay[0].copy()
+        h = int(res["hash"][0])
+        variants = []
+        for k in range(10):                                                            # a flipped byte somewhere in the payload
+            b = good.copy(); at = int(rng.integers(0, len(b))); b[at] ^= 0x41
+            variants.append(("flip@%d" % at, b, len(b), h, len(plain)))
+        b = good.copy(); b[4] ^= 0x08
+        variants.append(("first header", b, len(b), h, len(plain)))
+        variants.append(("comp_size - 5", good, len(good) - 5, h, len(plain)))
+        variants.append(("comp_size + 3", np.concatenate([good, np.zeros(8, np.uint8)]), len(good) + 3, h, len(plain)))
+        variants.append(("hash", good, len(good), h ^ 1, len(plain)))
+        variants.append(("capacity", good, len(good), h, len(plain) - 1))
+        variants.append(("intact", good, len(good), h, len(plain)))
+        for label, payload, csize, eh, cap in variants:
+            arc, offs, _ = _image([payload])
+            d = _descs(offs, [csize], [len(plain)], [eh], [(method, level)])
+            d["dst_capacity"] = cap
+            codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+            r1, out1 = codec.decode_batch_host(arc, d)
+            par = codec.decode_stats()["frame_parallel_entries"]
+            codec.set_option(OPT_DEC_SPLIT_MIN, 0)
+            r0, out0 = codec.decode_batch_host(arc, d)
+            key = (method, label)
+            assert int(r1["status"][0]) == int(r0["status"][0]), (key, r1, r0)
+            if r0["status"][0] == 0:
+                assert r1["hash"][0] == r0["hash"][0] and r1["produced"][0] == r0["produced"][0], key
+                assert np.array_equal(out1[0], out0[0]), key
+            if label == "intact":
+                assert par == 1 and r1["status"][0] == 0
+            if label == "hash":
+                assert par == 1 and r1["status"][0] == 15 and np.array_equal(out1[0][:len(plain)], plain), key    # the bytes stay, like the reference's
+            rc, out, got, hh = o.entry_decode(arc.tobytes(), int(offs[0]), csize, len(plain), eh, method, cap)
+            assert rc == int(r1["status"][0]), (key, rc, r1)
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+
+
+def test_big_entry_through_zpack_h_and_the_compiled_reference(tmp_path):
+    """zpack_write_file of a 24 MiB source (one call, one entry, 48 frames) and the streaming writer's entry of the same source: both
+    are read back by this library (frame-parallel) and by the compiled reference."""
+    from tests._libs import ZPackAPI
+    Z = ZPackAPI(zpack_amd.ZPACK_SO)
+    plain = dg.fill(dg.RECORDS, 8, 1, 24 * M + 99)
+    for method, level in [(METHOD_LZ4, 0), (METHOD_ZSTD, 3)]:
+        arc = Z.write_archive([("one", plain.tobytes())], method, level)
+        rc, r, keep = Z.open_memory(arc)
+        assert rc == 0
+        rc, out = Z.read_file(r, 0, len(plain))
+        assert rc == 0 and out == plain.tobytes()
+        Z.close_reader(r)
+        if have_ref():
+            R = ref()
+            rc, r, keep = R.open_memory(arc)
+            assert rc == 0
+            rc, out = R.read_file(r, 0, len(plain))
+            assert rc == 0 and out == plain.tobytes(), "the reference rejects the frame sequence"
+            R.close_reader(r)

@@ -663,3 +663,77 @@ def test_stream_roundtrips_random_sizes_and_windows(Z, tmp_path):
         arc, e = _stream_roundtrip(Z, tmp_path, plain, method, level, in_chunks, read_in, read_out, "r%d" % it, empty_update=bool(it & 1))
         rc, out, got, h = o.entry_decode(arc, e["offset"], e["comp_size"], size, e["hash"], method, max(size, 1))
         assert rc == 0 and np.array_equal(np.frombuffer(out, dtype=np.uint8, count=size), plain), (it, size, method, rc)
+
+
+def _count_frames(payload, method):
+    """frames in an entry's payload, walked by their own block headers (LZ4F: 64 KiB blocks, no checksums; Zstandard: single-segment
+    frames without checksum — the flavours the device encoder writes)"""
+    p = n = 0
+    b = payload
+    while p < len(b):
+        if method == METHOD_LZ4:
+            assert b[p:p + 4] == bytes([0x04, 0x22, 0x4D, 0x18]), p
+            p += 15 if b[p + 4] & 0x08 else 7                                          # (a piece of a sequence states its content size)
+            while True:
+                w = int.from_bytes(b[p:p + 4], "little"); p += 4
+                if w == 0:
+                    break
+                p += w & 0x7FFFFFFF
+        else:
+            assert b[p:p + 4] == bytes([0x28, 0xB5, 0x2F, 0xFD]), p
+            fhd = b[p + 4]
+            assert fhd & 0x20 and not fhd & 0x04
+            p += 5 + [1, 2, 4, 8][fhd >> 6]
+            while True:
+                w = int.from_bytes(b[p:p + 3], "little"); p += 3
+                p += 1 if (w >> 1) & 3 == 1 else w >> 3
+                if w & 1:
+                    break
+        n += 1
+    assert p == len(b)
+    return n
+
+
+def test_large_entries_are_written_as_frame_sequences(Z):
+    """zpack_write_files: an entry of >= 2 MiB goes to the device as 512 KiB pieces, one wave and one FRAME each, and its XXH3 is computed
+    by the whole chip (per-block partial sums + one chain) — sizes around the switch, around the piece and around XXH3's 1 KiB block /
+    64-byte stripe edges, every method; checked by the oracle, the compiled reference (both continue with the next frame, as
+    lib/zpack_read.c:380 and :414-439 do) and this library's own reader."""
+    M = 1 << 20
+    cases = [(METHOD_LZ4, 0, 2 * M - 1), (METHOD_LZ4, 0, 2 * M), (METHOD_LZ4, 0, 3 * M + 17), (METHOD_LZ4, 9, 2 * M + 1),
+             (METHOD_ZSTD, 3, 2 * M), (METHOD_ZSTD, 1, 5 * M - 1), (METHOD_ZSTD, 1, 2 * M + (512 << 10) + 1), (METHOD_ZSTD, 3, 100000),
+             (METHOD_NONE, 0, 4 * M), (METHOD_NONE, 0, 2 * M + 1023), (METHOD_NONE, 0, 2 * M + 1024), (METHOD_NONE, 0, 2 * M + 1025),
+             (METHOD_NONE, 0, 2 * M + 63), (METHOD_NONE, 0, 2 * M + 64), (METHOD_NONE, 0, 2 * M + 65), (METHOD_NONE, 0, 2 * M + 1),
+             (METHOD_LZ4, 0, 70000), (METHOD_ZSTD, 1, 9 * M + 12345)]
+    want, files = [], []
+    for i, (m, lv, n) in enumerate(cases):
+        want.append(("big%02d" % i, dg.fill([dg.TEXT, dg.RECORDS, dg.RANDOM, dg.RUNS][i % 4], 123, i, n).tobytes()))
+    # one zpack_write_files call with per-file options
+    w = Writer()
+    assert Z.lib.zpack_init_writer_heap(C.byref(w), 0) == 0
+    assert Z.lib.zpack_write_header(C.byref(w)) == 0 and Z.lib.zpack_write_data_header(C.byref(w)) == 0
+    opts = [CompressOptions(m, lv) for m, lv, _ in cases]
+    keep = [np.frombuffer(d, dtype=np.uint8) for _, d in want]
+    fl = (File * len(cases))()
+    for i, (name, d) in enumerate(want):
+        fl[i].filename = name.encode(); fl[i].buffer = C.cast(keep[i].ctypes.data, u8p); fl[i].size = len(d)
+        fl[i].options = C.pointer(opts[i]); fl[i].cctx = None
+    assert Z.lib.zpack_write_files(C.byref(w), fl, len(cases)) == 0
+    assert Z.lib.zpack_write_cdr(C.byref(w)) == 0 and Z.lib.zpack_write_eocdr(C.byref(w)) == 0
+    arc = bytes(C.cast(w.buffer, C.POINTER(C.c_uint8 * w.file_size)).contents)
+    Z.lib.zpack_close_writer(C.byref(w))
+    _decode_all_with_checkers(arc, want)
+    ents = zpk.parse(arc)
+    for e, (m, lv, n) in zip(ents, cases):
+        assert e["method"] == m
+        if m != METHOD_NONE:
+            frames = _count_frames(arc[e["offset"]:e["offset"] + e["comp_size"]], m)
+            assert frames == ((n + (512 << 10) - 1) // (512 << 10) if n >= 2 * M else 1), (m, n, frames)
+        else:
+            assert e["comp_size"] == n
+    rc, r, keepr = Z.open_memory(arc)
+    assert rc == 0 and r.file_count == len(want)
+    for i, (name, d) in enumerate(want):
+        rc, out = Z.read_file(r, i, max(1, len(d)))
+        assert rc == 0 and out[:len(d)] == d, (name, rc)
+    Z.close_reader(r)

@@ -19,10 +19,12 @@
 #include <pthread.h>
 #include <thread>
 #include <atomic>
+#include <vector>
 
 
 #include "zpk_device.h"
 #include "xxh3_device.h"
+#include "xxh3_span.h"
 #include "lz4_wave.h"
 #include "lz4_two.h"
 #include "lx_ring.h"
@@ -548,6 +550,9 @@ __global__ __launch_bounds__(256) void k_hash(const u8* __restrict__ src, const 
 // stage 2 over the output slot 8.8-9.4 ms (39 % fewer vector instructions, but bound by 128-byte line fetches for far match sources:
 // 5.8 TB/s through the fabric) or + stage 2 with the LDS window 11.5 ms (fabric reads -57 %, but bound by LDS cycles).  It stays in
 // the build, parity-tested on every fixture, as the measured basis for the next step (a cheaper executor behind pre-parsed records).
+#define ZPK_DEC_SPLIT_MIN_DEFAULT (2ull << 20)
+#define ZPK_ENC_SPLIT_MIN_DEFAULT (2ull << 20)
+#define ZPK_ENC_PIECE (512u << 10)                 // = ZPK_CS_PIECE of the streaming writer
 #ifndef ZPK_LZ4_TWO_STAGE_MIN_DEFAULT
 #define ZPK_LZ4_TWO_STAGE_MIN_DEFAULT 0x7FFFFFFFu
 #endif
@@ -583,6 +588,10 @@ struct zpk_codec {
     u8*  d_pack = nullptr;       u64 pack_cap = 0;     // K7: block sums + span index of the compaction
     u8*  d_packed = nullptr;     u64 packed_cap = 0;   // host encode path: packed payload stream
     u8*  d_packoff = nullptr;    u64 packoff_cap = 0;  // host encode path: payload offsets
+    u8*  d_xpart = nullptr;      u64 xpart_cap = 0;    // host encode path, split entries: span list | 64 bytes of XXH3 partial sums per 1 KiB block | hashes
+    u64  dec_split_min = ZPK_DEC_SPLIT_MIN_DEFAULT;    // ZPK_OPT_DEC_SPLIT_MIN: entries of at least this many bytes that ARE sequences of frames are decoded frame-parallel
+    u32  big_last[2] = {0, 0};                         // host decode path, most recent call: entries decoded frame-parallel, their frames
+    u64  enc_split_min = ZPK_ENC_SPLIT_MIN_DEFAULT;    // ZPK_OPT_ENC_SPLIT_MIN: entries of at least this many bytes are written as a sequence of frames
     u64* d_zarena = nullptr;     u64 zarena_cap = 0;   // decoder: pre-decoded Zstandard sequences, laid out like dst (zstd_fse4.h)
     u32* d_zstate = nullptr;     u64 zstate_cap = 0;   // decoder: per entry, 1 = its sequences are in the arena
     int lz4_hint = -1;           // host path: does the batch hold an LZ4 entry?  -1 = unknown (device path)
@@ -691,7 +700,7 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->s_up) (void)hipStreamDestroy(c->s_up);
     if (c->s_dn) (void)hipStreamDestroy(c->s_dn);
     for (int k = 0; k < 2 * 64; k++) if (c->pipe_ev[k]) (void)hipEventDestroy(c->pipe_ev[k]);
-    (void)hipFree(c->d_lz2arena); (void)hipFree(c->d_lz2info); (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_pack); (void)hipFree(c->d_packed); (void)hipFree(c->d_packoff);
+    (void)hipFree(c->d_lz2arena); (void)hipFree(c->d_lz2info); (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_pack); (void)hipFree(c->d_packed); (void)hipFree(c->d_packoff); (void)hipFree(c->d_xpart);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
@@ -728,6 +737,27 @@ int zpk_codec_device(const zpk_codec* c) { return c ? c->device : -1; }
 #define ZPK_DEV(x)
 #define ZPK_WD_ARG
 #endif
+
+// XXH3-64 of `nspans` long spans of `base` (xxh3_span.h): enqueues the two kernels and the copy of the hashes to `h_hash`
+static int xxh3_spans_launch(zpk_codec* c, const u8* base, const zpk_span* h_spans, u64 nspans, u64 part_blocks, u64* h_hash, hipStream_t st)
+{
+    if (nspans == 0) return ZPK_OK;
+    if (nspans > 0x7FFFFFFFull) return ZPK_E_INVALID;
+    const u64 span_bytes = (nspans * sizeof(zpk_span) + 255) & ~255ull, part_bytes = part_blocks * 64;
+    int rc;
+    if ((rc = grow(c, (void**)&c->d_xpart, &c->xpart_cap, span_bytes + part_bytes + nspans * 8 + 64))) return rc;
+    zpk_span* d_spans = (zpk_span*)c->d_xpart;
+    u64* d_part = (u64*)(c->d_xpart + span_bytes);
+    u64* d_hash = (u64*)(c->d_xpart + span_bytes + part_bytes);
+    HIPCHK(c, hipMemcpyAsync(d_spans, h_spans, nspans * sizeof(zpk_span), hipMemcpyHostToDevice, st));
+    const u64 ngroups = part_blocks / XS_GROUP;
+    if (ngroups) hipLaunchKernelGGL(k_xxh3_partials, dim3((u32)((ngroups + 3) / 4)), dim3(256), 0, st, base, (const zpk_span*)d_spans, (u32)nspans, ngroups, d_part);
+    hipLaunchKernelGGL(k_xxh3_chain, dim3((u32)nspans), dim3(64), 0, st, base, (const zpk_span*)d_spans, (const u64*)d_part, d_hash);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_hash, d_hash, nspans * 8, hipMemcpyDeviceToHost, st));
+    return ZPK_OK;
+}
+static inline u64 xxh3_span_blocks(u64 len) { return (((len - 1) >> 10) + XS_GROUP - 1) / XS_GROUP * XS_GROUP; }   // partial-sum slots of one span
 
 static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* read_lo, const u8* read_hi,
                          const zpk_decode_desc* desc, u64 n, u8* dst, u64 dst_size, zpk_decode_result* res, hipStream_t st)
@@ -1213,6 +1243,168 @@ static int decode_host_pipelined(zpk_codec* c, const u8* image, u64 image_size, 
 #define ZPK_HOST_CHUNK_BYTES (4ull << 30)        // output slots of one device sub-batch of the host path (an entry larger than this goes alone)
 #endif
 
+// ---- entries that are SEQUENCES OF FRAMES, decoded frame-parallel (host path) -----------------------------------------------------
+// One wave decodes one frame; an entry of hundreds of MiB in ONE frame is therefore one wave's work (~0.1 GB/s).  Entries written by
+// this library's own writer above 2 MiB (zpk_encode.inc, zpk_stream.inc) are sequences of 512 KiB frames that each state their
+// content size: the host walks the frames' block headers (4 / 3 bytes per block, in the caller's archive image), and when the frames
+// tile the entry exactly — >= 2 of them, every one with its content size, the sizes summing to uncomp_size — they go to the device
+// as a batch of their own, every frame a sub-entry with its own output range; the entry's XXH3 is computed over the assembled
+// output by the whole chip (xxh3_span.h).  Large stored entries are cut into 512 KiB slices the same way.  Anything else — a single
+// frame, a frame without content size, skippable frames, trailing bytes, a guard of lib/zpack_read.c:328-348 that would fire — stays
+// with the one-wave decoders, and so does every entry one of whose frames fails here: verdicts come from one place only.
+struct BigSub { u64 src_off, comp, out_off, size; };                  // a frame: byte ranges relative to its entry
+struct BigEntry { u64 idx, first_sub, nsub; };
+static inline u32 hrd32(const u8* p) { u32 v; memcpy(&v, p, 4); return v; }
+static inline u64 hrd64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
+
+static bool walk_lz4_frames(const u8* p, u64 comp, u64 uncomp, std::vector<BigSub>& subs)
+{
+    const size_t start = subs.size();
+    u64 ip = 0, out = 0;
+    while (ip < comp) {
+        if (comp - ip < 15 + 4 || hrd32(p + ip) != 0x184D2204u) goto other;
+        {
+            const u8 flg = p[ip + 4];
+            if ((flg >> 6) != 1 || (flg & 0x03) || !(flg & 0x08)) goto other;        // version 01, no reserved bit, no dictionary, content size present
+            const u64 csz = hrd64(p + ip + 6);
+            u64 q = ip + 15;
+            for (;;) {
+                if (comp - q < 4) goto other;
+                const u32 w = hrd32(p + q); q += 4;
+                if (w == 0) break;
+                const u64 nb = (u64)(w & 0x7FFFFFFFu) + ((flg & 0x10) ? 4 : 0);
+                if (nb > comp - q) goto other;
+                q += nb;
+            }
+            if (flg & 0x04) { if (comp - q < 4) goto other; q += 4; }
+            if (csz == 0 || csz > uncomp - out || (out & 255)) goto other;           // (output ranges start on 256-byte boundaries, like the slots of any batch)
+            subs.push_back(BigSub{ ip, q - ip, out, csz });
+            out += csz; ip = q;
+        }
+    }
+    if (out == uncomp && subs.size() - start >= 2) return true;
+other:
+    subs.resize(start);
+    return false;
+}
+
+static bool walk_zstd_frames(const u8* p, u64 comp, u64 uncomp, std::vector<BigSub>& subs)
+{
+    const size_t start = subs.size();
+    u64 ip = 0, out = 0;
+    while (ip < comp) {
+        if (comp - ip < 4 + 1 + 1 + 3 || hrd32(p + ip) != 0xFD2FB528u) goto other;
+        {
+            const u8 fhd = p[ip + 4];
+            const u32 fcs_flag = fhd >> 6, ss = (fhd >> 5) & 1, did = fhd & 3;
+            if (fhd & 0x08) goto other;                                               // reserved bit
+            const u32 fcs_bytes = fcs_flag == 0 ? ss : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+            if (!fcs_bytes) goto other;                                               // no content size: its output cannot be placed
+            u64 q = ip + 5 + (ss ? 0 : 1) + (did == 3 ? 4 : did);
+            if (q > comp || comp - q < fcs_bytes) goto other;
+            u64 fcs = 0;
+            for (u32 i = 0; i < fcs_bytes; i++) fcs |= (u64)p[q + i] << (8 * i);
+            if (fcs_bytes == 2) fcs += 256;
+            q += fcs_bytes;
+            for (;;) {
+                if (comp - q < 3) goto other;
+                const u32 w = (u32)p[q] | ((u32)p[q + 1] << 8) | ((u32)p[q + 2] << 16); q += 3;
+                const u32 type = (w >> 1) & 3;
+                if (type == 3) goto other;
+                const u64 nb = type == 1 ? 1 : (w >> 3);
+                if (nb > comp - q) goto other;
+                q += nb;
+                if (w & 1) break;
+            }
+            if (fhd & 0x04) { if (comp - q < 4) goto other; q += 4; }
+            if (fcs == 0 || fcs > uncomp - out || (out & 255)) goto other;
+            subs.push_back(BigSub{ ip, q - ip, out, fcs });
+            out += fcs; ip = q;
+        }
+    }
+    if (out == uncomp && subs.size() - start >= 2) return true;
+other:
+    subs.resize(start);
+    return false;
+}
+
+// the frames of entries [g0, g1) of `be` as one device batch; redo[k] = 1: entry k takes the serial path after all
+static int decode_big_group(zpk_codec* c, const u8* archive, const zpk_decode_desc* desc, const BigEntry* be, u64 g0, u64 g1,
+                            const std::vector<BigSub>& subs, uint8_t* const* dst_ptrs, zpk_decode_result* results, u8* redo)
+{
+    const u64 ng = g1 - g0;
+    u64 nsub = 0;
+    for (u64 k = g0; k < g1; k++) nsub += be[k].nsub;
+    std::vector<u64> coff(ng + 1), ooff(ng + 1);
+    std::vector<zpk_span> spans(ng);
+    std::vector<u64> h_hash(ng);
+    std::vector<zpk_decode_desc> hd(nsub);
+    std::vector<zpk_decode_result> hr(nsub);
+    std::vector<const uint8_t*> cptr(ng);
+    u64 ct = 0, ot = 0, part_blocks = 0, j = 0;
+    int has_zstd = 0, has_lz4 = 0;
+    for (u64 k = 0; k < ng; k++) {
+        const BigEntry& E = be[g0 + k];
+        const zpk_decode_desc& d = desc[E.idx];
+        coff[k] = ct; ooff[k] = ot; cptr[k] = archive + d.src_offset;
+        for (u64 f = 0; f < E.nsub; f++, j++) {
+            const BigSub& S = subs[E.first_sub + f];
+            zpk_decode_desc& x = hd[j];
+            x.src_offset = ct + S.src_off; x.comp_size = S.comp; x.uncomp_size = S.size; x.expect_hash = 0;
+            x.dst_offset = ot + S.out_off; x.dst_capacity = S.size; x.method = d.method; x.flags = ZPK_DF_SKIP_HASH;
+        }
+        spans[k].off = ot; spans[k].len = d.uncomp_size; spans[k].part_base = part_blocks;
+        part_blocks += xxh3_span_blocks(d.uncomp_size);
+        ct += (d.comp_size + 255) & ~255ull; ot += (d.uncomp_size + 255) & ~255ull;
+        if (d.method == ZPK_METHOD_ZSTD) has_zstd = 1;
+        if (d.method == ZPK_METHOD_LZ4) has_lz4 = 1;
+    }
+    coff[ng] = ct; ooff[ng] = ot;
+    int rc;
+    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, ct + ZPK_SRC_SLACK)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, ot + 16)) ||
+        (rc = grow(c, &c->d_desc, &c->desc_cap, nsub * sizeof(zpk_decode_desc))) ||
+        (rc = grow(c, &c->d_res, &c->res_cap, nsub * sizeof(zpk_decode_result)))) return rc;
+    hipError_t e = hipSuccess;
+    if (ng == 1) e = hipMemcpyAsync(c->d_src, cptr[0], desc[be[g0].idx].comp_size, hipMemcpyHostToDevice, c->stream);
+    else {
+        const int grc = h2d_gather(c, c->d_src, ct, ng, cptr.data(), [&](u64 k) { return coff[k]; }, [&](u64 k) { return (u64)desc[be[g0 + k].idx].comp_size; }, e, c->stream);
+        if (grc) return grc;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_desc, hd.data(), nsub * sizeof(zpk_decode_desc), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    c->zstd_hint = has_zstd; c->lz4_hint = has_lz4;
+    // (image size = the staged bytes + 1: the last frame still passes the `offset + comp_size < file_size` guard of :331)
+    rc = decode_launch(c, c->d_src, ct + 1, c->d_src, c->d_src + ct + ZPK_SRC_READ_SLACK, (const zpk_decode_desc*)c->d_desc, nsub,
+                       c->d_dst, ot, (zpk_decode_result*)c->d_res, c->stream);
+    if (rc) return rc;
+    if ((rc = xxh3_spans_launch(c, c->d_dst, spans.data(), ng, part_blocks, h_hash.data(), c->stream))) return rc;
+    e = hipMemcpyAsync(hr.data(), c->d_res, nsub * sizeof(zpk_decode_result), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "decode: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    j = 0;
+    for (u64 k = 0; k < ng; k++) {
+        const BigEntry& E = be[g0 + k];
+        const zpk_decode_desc& d = desc[E.idx];
+        bool ok = true;
+        for (u64 f = 0; f < E.nsub; f++, j++) if (hr[j].status != 0 || hr[j].produced != subs[E.first_sub + f].size) ok = false;
+        redo[g0 + k] = ok ? 0 : 1;
+        if (!ok) continue;
+        zpk_decode_result& r = results[E.idx];
+        r.hash = h_hash[k]; r.produced = d.uncomp_size; r.detail = 0;
+        r.status = ((d.flags & ZPK_DF_SKIP_HASH) || r.hash == d.expect_hash) ? 0 : 15;          // ZPACK_ERROR_FILE_HASH_MISMATCH, lib/zpack_read.c:467
+        c->big_last[0]++; c->big_last[1] += (u32)E.nsub;
+    }
+    std::vector<uint8_t*> optr(ng);
+    for (u64 k = 0; k < ng; k++) optr[k] = dst_ptrs[be[g0 + k].idx];
+    rc = d2h_scatter(c, c->d_dst, ot, ng, optr.data(), [&](u64 k) { return ooff[k]; }, [&](u64 k) { return redo[g0 + k] ? 0ull : (u64)desc[be[g0 + k].idx].uncomp_size; }, e);
+    if (rc) return rc;
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "D2H: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    return ZPK_OK;
+}
+
+static int decode_batch_host_plain(zpk_codec* c, const uint8_t* archive, uint64_t archive_size, const zpk_decode_desc* desc, uint64_t n,
+                                   uint8_t* const* dst_ptrs, zpk_decode_result* results);
+
 int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t archive_size, const zpk_decode_desc* desc, uint64_t n,
                                 uint8_t* const* dst_ptrs, zpk_decode_result* results)
 {
@@ -1220,6 +1412,70 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
     if (n == 0) return ZPK_OK;
     CodecLock lk(c);
     HIPCHK(c, hipSetDevice(c->device));
+    c->big_last[0] = c->big_last[1] = 0;
+    // ---- which entries are sequences of frames worth decoding frame-parallel ----
+    std::vector<BigEntry> be;
+    std::vector<BigSub> subs;
+    if (archive && c->dec_split_min != ~0ull) {
+        try {
+            for (u64 i = 0; i < n; i++) {
+                const zpk_decode_desc& d = desc[i];
+                if (d.uncomp_size < c->dec_split_min || d.uncomp_size > ZPK_HOST_CHUNK_BYTES || d.method > ZPK_METHOD_LZ4) continue;
+                // every guard of lib/zpack_read.c:328-348 must pass: an entry that earns a verdict there gets it from the usual path
+                if (!d.comp_size || d.src_offset > archive_size || d.comp_size >= archive_size - d.src_offset || d.dst_capacity < d.uncomp_size) continue;
+                const size_t s0 = subs.size();
+                bool ok = false;
+                if (d.method == ZPK_METHOD_NONE) {
+                    if (d.comp_size == d.uncomp_size && d.uncomp_size > ZPK_ENC_PIECE) {
+                        for (u64 o = 0; o < d.uncomp_size; o += ZPK_ENC_PIECE) {
+                            const u64 len = d.uncomp_size - o < ZPK_ENC_PIECE ? d.uncomp_size - o : (u64)ZPK_ENC_PIECE;
+                            subs.push_back(BigSub{ o, len, o, len });
+                        }
+                        ok = true;
+                    }
+                } else if (d.method == ZPK_METHOD_LZ4) ok = walk_lz4_frames(archive + d.src_offset, d.comp_size, d.uncomp_size, subs);
+                else ok = walk_zstd_frames(archive + d.src_offset, d.comp_size, d.uncomp_size, subs);
+                if (ok) be.push_back(BigEntry{ i, (u64)s0, (u64)(subs.size() - s0) });
+            }
+        } catch (...) { be.clear(); subs.clear(); }                                   // out of host memory for the plan: the usual path
+    }
+    if (be.empty()) {
+        const int rc = decode_batch_host_plain(c, archive, archive_size, desc, n, dst_ptrs, results);
+        c->zstd_hint = -1; c->lz4_hint = -1;
+        return rc;
+    }
+    int rc = ZPK_OK;
+    try {
+        std::vector<u8> redo(be.size(), 0), is_big(n, 0);
+        for (u64 g0 = 0; g0 < be.size() && rc == ZPK_OK; ) {                          // groups by the size of their output
+            u64 g1 = g0, out = 0;
+            while (g1 < be.size() && (g1 == g0 || out + desc[be[g1].idx].uncomp_size <= ZPK_HOST_CHUNK_BYTES)) { out += (desc[be[g1].idx].uncomp_size + 255) & ~255ull; g1++; }
+            rc = decode_big_group(c, archive, desc, be.data(), g0, g1, subs, dst_ptrs, results, redo.data());
+            g0 = g1;
+        }
+        // ---- everything else, and the entries a frame of which did not decode, through the usual path ----
+        for (u64 k = 0; k < be.size(); k++) if (!redo[k]) is_big[be[k].idx] = 1;
+        std::vector<u64> rest;
+        for (u64 i = 0; i < n; i++) if (!is_big[i]) rest.push_back(i);
+        if (rc == ZPK_OK && !rest.empty()) {
+            std::vector<zpk_decode_desc> rd(rest.size());
+            std::vector<uint8_t*> rp(rest.size());
+            std::vector<zpk_decode_result> rr(rest.size());
+            for (u64 k = 0; k < rest.size(); k++) { rd[k] = desc[rest[k]]; rp[k] = dst_ptrs[rest[k]]; }
+            const u32 keep0 = c->big_last[0], keep1 = c->big_last[1];
+            rc = decode_batch_host_plain(c, archive, archive_size, rd.data(), rest.size(), rp.data(), rr.data());
+            c->big_last[0] = keep0; c->big_last[1] = keep1;
+            if (rc == ZPK_OK) for (u64 k = 0; k < rest.size(); k++) results[rest[k]] = rr[k];
+        }
+    } catch (...) { rc = ZPK_E_NOMEM; }
+    c->zstd_hint = -1; c->lz4_hint = -1;
+    return rc;
+}
+
+static int decode_batch_host_plain(zpk_codec* c, const uint8_t* archive, uint64_t archive_size, const zpk_decode_desc* desc, uint64_t n,
+                                   uint8_t* const* dst_ptrs, zpk_decode_result* results)
+{
+    if (n == 0) return ZPK_OK;
     zpk_decode_desc* hd = (zpk_decode_desc*)malloc(n * sizeof(zpk_decode_desc));
     if (!hd) return ZPK_E_NOMEM;
     int rc = ZPK_OK;
@@ -1349,6 +1605,7 @@ int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
     memset(out, 0, 16 * sizeof(uint32_t));
     out[0] = h[C_RETRY_LZ4]; out[1] = h[C_RETRY_ZSTD];
     out[2] = h[C_LZ4_TWO_OK]; out[3] = h[C_LZ4_LEFT]; out[4] = (u32)c->lz4_two_last;
+    out[5] = c->big_last[0]; out[6] = c->big_last[1];
     return ZPK_OK;
 }
 
@@ -1373,6 +1630,8 @@ int zpk_codec_set_option(zpk_codec* c, int option, int value)
     if (option == ZPK_OPT_LZ4_TWO_STAGE_MIN) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_min = (u32)value; return ZPK_OK; }
     if (option == ZPK_OPT_LZ4_EXEC_WINDOW) { c->lz4_exec_window = value ? 1 : 0; return ZPK_OK; }
     if (option == ZPK_OPT_DEV_LZ4_EXEC_PAD) { if (value < 0 || value > (120 << 10)) return ZPK_E_INVALID; c->lz4_exec_pad = (u32)value; return ZPK_OK; }
+    if (option == ZPK_OPT_DEC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->dec_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
+    if (option == ZPK_OPT_ENC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->enc_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_max_comp = (u32)value; return ZPK_OK; }
     return ZPK_E_INVALID;
 }
