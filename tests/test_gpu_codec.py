@@ -502,3 +502,40 @@ def test_stream_steps_agree_with_one_shot_on_foreign_and_damaged_frames(codec, g
         assert status == want_rc, (label, "one-shot", want_rc, "stream", status)
         if want_rc in (0, 15):
             assert got == outs[0][:min(produced, usize)].tobytes(), label
+
+
+def test_work_lists_largest_first_give_identical_results(codec):
+    """A ragged batch (200 B ... 300 KiB, both methods + damaged and refused entries) decoded with its work lists in archive order and
+    largest entries first (ZPK_OPT_ORDER_MIN: the device counting sort behind the classification): identical statuses, hashes, produced
+    counts and bytes; and every entry is on exactly one list position (nothing lost, nothing twice — the output of a skipped entry
+    would stay zero)."""
+    import torch
+    n = 6000
+    b = dg.Batch(n, 200, 300000, method=dg.COIN, level=3, seed=21)
+    desc, total = zpack_amd.decode_descs_from_batch(b)
+    desc = desc.copy()
+    arc = b.archive.copy()
+    rng = np.random.default_rng(4)
+    for i in rng.choice(n, 40, replace=False):                                          # damaged payloads
+        arc[int(desc["src_offset"][i]) + int(rng.integers(0, int(desc["comp_size"][i])))] ^= 0x5A
+    for i in rng.choice(n, 20, replace=False):                                          # refused by the guards
+        desc["dst_capacity"][i] = desc["uncomp_size"][i] - 1
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(arc).to(dev)
+    ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    got = []
+    for order_min in (1, 0):
+        codec.set_option(zpack_amd.OPT_ORDER_MIN, order_min)
+        dst = torch.zeros(total, dtype=torch.uint8, device=dev)
+        dres = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        codec.decode_batch_device(src, ddesc, n, dst, dres)
+        torch.cuda.synchronize()
+        got.append((dres.cpu().numpy().view(zpack_amd.DECODE_RESULT).copy(), dst.cpu().numpy().copy()))
+    codec.set_option(zpack_amd.OPT_ORDER_MIN, 8192)
+    (r1, o1), (r0, o0) = got
+    assert np.array_equal(r1["status"], r0["status"]) and np.array_equal(r1["produced"], r0["produced"])
+    ok = r0["status"] == 0
+    assert ok.sum() >= n - 60 and np.array_equal(r1["hash"][ok], r0["hash"][ok]) and np.array_equal(r1["hash"][ok], b.hashes[ok])
+    for i in np.flatnonzero(ok):
+        lo = int(desc["dst_offset"][i]); hi = lo + int(desc["uncomp_size"][i])
+        assert np.array_equal(o1[lo:hi], o0[lo:hi]), i

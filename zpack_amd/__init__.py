@@ -18,7 +18,7 @@ METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
 DF_GENERAL = 2
 K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_LZ4_PARSE, K_ENCODE = 0, 1, 2, 3, 4, 5, 6, 7
-OPT_LZ4_TWO_STAGE_MIN, OPT_LZ4_TWO_STAGE_MAX_COMP, OPT_DEV_LZ4_EXEC_PAD, OPT_LZ4_EXEC_WINDOW, OPT_ENC_SPLIT_MIN, OPT_DEC_SPLIT_MIN = 2, 3, 4, 5, 6, 7      # zpk_codec_set_option (include/zpack_codec.h)
+OPT_LZ4_TWO_STAGE_MIN, OPT_LZ4_TWO_STAGE_MAX_COMP, OPT_DEV_LZ4_EXEC_PAD, OPT_LZ4_EXEC_WINDOW, OPT_ENC_SPLIT_MIN, OPT_DEC_SPLIT_MIN, OPT_ORDER_MIN = 2, 3, 4, 5, 6, 7, 8      # zpk_codec_set_option (include/zpack_codec.h)
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
 DECODE_DESC = np.dtype([("src_offset", "<u8"), ("comp_size", "<u8"), ("uncomp_size", "<u8"), ("expect_hash", "<u8"),

@@ -46,11 +46,20 @@ enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT =
        C_LZ4_LEFT = 21, C_LZ4_LEFT_HEAD = 22,   // two-stage LZ4 path: entries handed to the general decoder, its dequeue head
        C_LZ4_TWO_OK = 23,                       // entries finished by the two-stage path
        C_LZ4_BUMP = 24,                         // (two words, 8-byte aligned) record-arena allocator of k_lz4_parse
-       N_COUNTERS = 32 };
-enum { N_LISTS_ALLOC = N_LISTS + 3 };           // + the two retry lists + what the two-stage LZ4 path leaves to the general decoder
+       C_ORDER_SPAN = 26,                       // (two words) largest size class and largest 15 - class among the Zstandard / LZ4 entries
+       C_ORDER = 32,                            // k_order_*: [2 lists][16 size classes] entry counts, then the same again as fill cursors
+       N_COUNTERS = 32 + 64 };
+enum { N_LISTS_ALLOC = N_LISTS + 5 };           // + the two retry lists + what the two-stage LZ4 path leaves to the general decoder + the two ordered lists
 
 // ------------------------------------------------------------------------------------ kernels
 
+#define ORD_CLASSES 16
+__device__ __forceinline__ int order_class(u64 size)
+{
+    const int lg = 63 - __clzll((long long)(size | 1));
+    const int b = 26 - lg;                                                            // >= 64 MiB: class 0 ... < 4 KiB: class 15
+    return b < 0 ? 0 : (b > ORD_CLASSES - 1 ? ORD_CLASSES - 1 : b);
+}
 __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restrict__ desc, u64 n, u64 src_size, u64 dst_size,
                                                   zpk_decode_result* __restrict__ res, u32* __restrict__ lists, u64 list_stride,
                                                   u32* __restrict__ counters)
@@ -81,6 +90,13 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
     if (live) res[i] = r;
     // wave-aggregated append: one atomic per list per wave (a per-lane atomicAdd on three hot words cost 1.1 ms / 100k entries)
     const int lane = lane_id();
+    {   // the span of size classes among the entries that go to a decoder (k_order_*)
+        const bool dec = list == L_ZSTD || list == L_LZ4;
+        u32 hi = dec ? (u32)order_class(d.uncomp_size) + 1u : 0u, inv = dec ? (u32)(ORD_CLASSES - order_class(d.uncomp_size)) : 0u;   // (+1: 0 = none)
+        #pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { const u32 a = (u32)__shfl_xor((int)hi, m, 64), b2 = (u32)__shfl_xor((int)inv, m, 64); hi = a > hi ? a : hi; inv = b2 > inv ? b2 : inv; }
+        if (lane == 0 && hi) { atomicMax(&counters[C_ORDER_SPAN], hi - 1u); atomicMax(&counters[C_ORDER_SPAN + 1], inv - 1u); }
+    }
     #pragma unroll
     for (int L = 0; L < N_LISTS; L++) {
         const u64 m = __ballot(list == L);
@@ -90,6 +106,79 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
         if (lane == leader) base = atomicAdd(&counters[L], (u32)__popcll(m));
         base = (u32)__shfl((int)base, leader, 64);
         if (list == L) lists[(u64)L * list_stride + base + (u32)__popcll(m & ((1ull << lane) - 1))] = (u32)i;
+    }
+}
+
+// ---- largest entries first -----------------------------------------------------------------------------------------------------
+// One wave (or one FSE row) works on one entry, and a batch is only a few rounds of the resident waves: with entries of 4 KiB ... 1 MiB
+// in archive order, a 1 MiB entry that starts in the last round runs on alone for its whole length while the rest of the chip idles.
+// The Zstandard and LZ4 work lists are therefore re-ordered by size class (floor(log2 uncomp_size), largest first: longest
+// processing time first) with a two-kernel counting sort — per-workgroup LDS histograms, one global atomic per class and
+// workgroup; entries of one class keep their neighbourhood.  (Uniform batches come out in nearly the order they went in.)
+// (k_classify leaves the largest class and the largest 15 - class it saw in counters[C_ORDER_SPAN], [C_ORDER_SPAN + 1]: a batch of ONE
+// class — the uniform workloads — is copied through in its own order.)
+__device__ __forceinline__ bool order_single_class(const u32* counters) { return counters[C_ORDER_SPAN] + counters[C_ORDER_SPAN + 1] == ORD_CLASSES - 1; }
+// rank of this lane among the lanes of its wave with the same class (in lane order), and how many there are
+__device__ __forceinline__ void order_wave_rank(int b, int lane, u32& rank, u32& count)
+{
+    rank = 0; count = 0;
+    u64 todo = __ballot(b >= 0);
+    while (todo) {
+        const int cls = __shfl(b, __ffsll((long long)todo) - 1, 64);
+        const u64 m = __ballot(b == cls);
+        if (b == cls) { rank = (u32)__popcll(m & ((1ull << lane) - 1)); count = (u32)__popcll(m); }
+        todo &= ~m;
+    }
+}
+__global__ __launch_bounds__(256) void k_order_count(const zpk_decode_desc* __restrict__ desc, const u32* __restrict__ lists, u64 list_stride,
+                                                     u32* __restrict__ counters)
+{
+    __shared__ u32 h[ORD_CLASSES];
+    const int L = blockIdx.y == 0 ? L_ZSTD : L_LZ4;
+    const u32 cnt = counters[L];
+    if ((u64)blockIdx.x * 256 >= cnt || order_single_class(counters)) return;
+    if (threadIdx.x < ORD_CLASSES) h[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id();
+    const int b = k < cnt ? order_class(desc[lists[(u64)L * list_stride + k]].uncomp_size) : -1;
+    u32 rank, count;
+    order_wave_rank(b, lane, rank, count);
+    if (b >= 0 && rank == 0) atomicAdd(&h[b], count);
+    __syncthreads();
+    if (threadIdx.x < ORD_CLASSES && h[threadIdx.x]) atomicAdd(&counters[C_ORDER + blockIdx.y * ORD_CLASSES + threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_order_fill(const zpk_decode_desc* __restrict__ desc, const u32* __restrict__ lists, u64 list_stride,
+                                                    u32* __restrict__ ordered /* two lists of list_stride */, u32* __restrict__ counters)
+{
+    __shared__ u32 wcount[4][ORD_CLASSES], base[ORD_CLASSES];
+    const int L = blockIdx.y == 0 ? L_ZSTD : L_LZ4;
+    const u32 cnt = counters[L];
+    if ((u64)blockIdx.x * 256 >= cnt) return;
+    const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (order_single_class(counters)) { if (k < cnt) ordered[(u64)blockIdx.y * list_stride + k] = lists[(u64)L * list_stride + k]; return; }
+    if (threadIdx.x < 4 * ORD_CLASSES) (&wcount[0][0])[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    u32 e = 0; int b = -1;
+    if (k < cnt) { e = lists[(u64)L * list_stride + k]; b = order_class(desc[e].uncomp_size); }
+    u32 rank, count;
+    order_wave_rank(b, lane, rank, count);
+    if (b >= 0 && rank == 0) wcount[w][b] = count;
+    __syncthreads();
+    if (threadIdx.x < ORD_CLASSES) {                                                   // this workgroup's range of the class: entries stay in list order inside it
+        const int c = threadIdx.x;
+        const u32 total = wcount[0][c] + wcount[1][c] + wcount[2][c] + wcount[3][c];
+        const u32* const hist = counters + C_ORDER + blockIdx.y * ORD_CLASSES;
+        u32 before = 0;
+        for (int j = 0; j < c; j++) before += hist[j];
+        base[c] = total ? before + atomicAdd(&counters[C_ORDER + 2 * ORD_CLASSES + blockIdx.y * ORD_CLASSES + c], total) : 0;
+    }
+    __syncthreads();
+    if (b >= 0) {
+        u32 at = base[b] + rank;
+        for (int j = 0; j < w; j++) at += wcount[j][b];
+        ordered[(u64)blockIdx.y * list_stride + at] = e;
     }
 }
 
@@ -589,6 +678,7 @@ struct zpk_codec {
     u8*  d_packed = nullptr;     u64 packed_cap = 0;   // host encode path: packed payload stream
     u8*  d_packoff = nullptr;    u64 packoff_cap = 0;  // host encode path: payload offsets
     u8*  d_xpart = nullptr;      u64 xpart_cap = 0;    // host encode path, split entries: span list | 64 bytes of XXH3 partial sums per 1 KiB block | hashes
+    u64  order_min = 8192;                             // ZPK_OPT_ORDER_MIN: decode batches of at least this many entries run their work lists largest entries first
     u64  dec_split_min = ZPK_DEC_SPLIT_MIN_DEFAULT;    // ZPK_OPT_DEC_SPLIT_MIN: entries of at least this many bytes that ARE sequences of frames are decoded frame-parallel
     u32  big_last[2] = {0, 0};                         // host decode path, most recent call: entries decoded frame-parallel, their frames
     u64  enc_split_min = ZPK_ENC_SPLIT_MIN_DEFAULT;    // ZPK_OPT_ENC_SPLIT_MIN: entries of at least this many bytes are written as a sequence of frames
@@ -795,6 +885,16 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     ZPK_KEV(ZPK_K_CLASSIFY, 0);
     hipLaunchKernelGGL(k_classify, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, desc, n, src_size, dst_size, res,
                        c->d_lists, stride, c->d_counters);
+    // largest entries first (see k_order_count); batches that fit the resident waves in one round have nothing to order
+    const u32* zstd_list = c->d_lists + L_ZSTD * stride;
+    const u32* lz4_list = c->d_lists + L_LZ4 * stride;
+    if (n >= c->order_min) {
+        u32* const ordered = c->d_lists + (u64)(N_LISTS + 3) * stride;
+        const dim3 og((u32)((n + 255) / 256), 2);
+        hipLaunchKernelGGL(k_order_count, og, dim3(256), 0, st, desc, (const u32*)c->d_lists, stride, c->d_counters);
+        hipLaunchKernelGGL(k_order_fill, og, dim3(256), 0, st, desc, (const u32*)c->d_lists, stride, ordered, c->d_counters);
+        zstd_list = ordered; lz4_list = ordered + stride;
+    }
     ZPK_KEV(ZPK_K_CLASSIFY, 1);
     ZPK_TRACE_STEP("k_classify");
     const u32 wgrid = (u32)((n + 3) / 4);          // one wave per list slot
@@ -841,7 +941,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     auto launch_lz4 = [&]() {
         if (c->profiling) (void)hipEventRecord(c->kev[ZPK_K_LZ4][0], sl);
         if (!(skip & 2) && maybe_lz4 && lz4_two) {
-            const u32* const l4 = (const u32*)(c->d_lists + L_LZ4 * stride);
+            const u32* const l4 = lz4_list;
             if (c->profiling) (void)hipEventRecord(c->kev[ZPK_K_LZ4_PARSE][0], sl);
             hipLaunchKernelGGL(k_lz4_parse, dim3((u32)((n + 63) / 64)), dim3(64), 0, sl, src, read_lo, read_hi, desc, l4, c->d_counters,
                                c->d_lz2arena, arena_recs, (Lz2Info*)c->d_lz2info, c->lz4_two_max_comp);
@@ -858,7 +958,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
                                (const u32*)retry_lz4, c->d_counters, c->d_dbg);
         } else if (!(skip & 2) && maybe_lz4) {
             hipLaunchKernelGGL(k_lz4_wave, dim3((u32)n), dim3(64), 0, sl, src, read_lo, read_hi, desc, dst, res,
-                               (const u32*)(c->d_lists + L_LZ4 * stride), c->d_counters, c->d_dbg, retry_lz4 ZPK_WD_ARG);
+                               lz4_list, c->d_counters, c->d_dbg, retry_lz4 ZPK_WD_ARG);
             // entries whose decoder ran out of its time budget: again, with ZPK_WATCHDOG_RETRY_SCALE times the budget (a small grid
             // that leaves at once when the list is empty — the normal case)
             hipLaunchKernelGGL(k_lz4_retry, dim3((u32)(n < 256 ? n : 256)), dim3(64), 0, sl, src, read_lo, read_hi, desc, dst, res,
@@ -887,17 +987,17 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
         HIPCHK(c, hipMemsetAsync(c->d_zstate, 0, n * sizeof(u32), st));          // entries k_zstd_fse never reaches stay unmarked
         const u64 zwaves = (n + ZF_ROWS - 1) / ZF_ROWS;
         hipLaunchKernelGGL(k_zstd_fse, dim3((u32)(zwaves < ZF_GRID_MAX ? zwaves : ZF_GRID_MAX)), dim3(64), 0, st, src, desc,
-                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_zarena, c->d_zstate);
+                           zstd_list, c->d_counters, c->d_zarena, c->d_zstate);
     }
     ZPK_KEV(ZPK_K_ZSTD_FSE, 1);
     ZPK_TRACE_STEP("k_zstd_fse");
     ZPK_KEV(ZPK_K_ZSTD, 0);
     if (!(skip & 4) && two_stage)
         hipLaunchKernelGGL(k_zstd_exec, dim3(exec_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
-                           c->d_lists + L_ZSTD * stride, c->d_counters, c->d_lit, c->d_zarena, c->d_zstate, leftover, c->d_dbg);
+                           zstd_list, c->d_counters, c->d_lit, c->d_zarena, c->d_zstate, leftover, c->d_dbg);
     if (!(skip & 4) && maybe_zstd)
         hipLaunchKernelGGL(k_zstd, dim3(zstd_grid), dim3(ZSTD_WG_THREADS), 0, st, src, desc, dst, res,
-                       two_stage ? (const u32*)leftover : (const u32*)(c->d_lists + L_ZSTD * stride), c->d_counters, c->d_lit, c->d_dbg,
+                       two_stage ? (const u32*)leftover : zstd_list, c->d_counters, c->d_lit, c->d_dbg,
                        two_stage ? (int)C_LEFT_COUNT : (int)L_ZSTD, (int)(L_COUNT + L_ZSTD), retry_zstd, (int)C_RETRY_ZSTD, wd_scale);
     ZPK_KEV(ZPK_K_ZSTD, 1);
     ZPK_TRACE_STEP("k_zstd");
@@ -1630,6 +1730,7 @@ int zpk_codec_set_option(zpk_codec* c, int option, int value)
     if (option == ZPK_OPT_LZ4_TWO_STAGE_MIN) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_min = (u32)value; return ZPK_OK; }
     if (option == ZPK_OPT_LZ4_EXEC_WINDOW) { c->lz4_exec_window = value ? 1 : 0; return ZPK_OK; }
     if (option == ZPK_OPT_DEV_LZ4_EXEC_PAD) { if (value < 0 || value > (120 << 10)) return ZPK_E_INVALID; c->lz4_exec_pad = (u32)value; return ZPK_OK; }
+    if (option == ZPK_OPT_ORDER_MIN) { if (value < 0) return ZPK_E_INVALID; c->order_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_DEC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->dec_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_ENC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->enc_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_max_comp = (u32)value; return ZPK_OK; }
