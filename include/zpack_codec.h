@@ -133,7 +133,8 @@ int         zpk_codec_device(const zpk_codec* c);
  *                                   is decoded by one wave as before (verdicts come from there only).  Default 2 MiB; 0 = never.
  *   ZPK_OPT_ORDER_MIN               decode batches of at least `value` entries run their Zstandard and LZ4 work lists LARGEST ENTRIES
  *                                   FIRST (size classes by powers of two; a device counting sort behind the classification): one
- *                                   wave works on one entry, so a large entry that starts last runs on alone.  Default 8192; 0 = never. */
+ *                                   wave works on one entry, so a large entry that starts last runs on alone; encode batches order
+ *                                   their ticket queue the same way.  Default 8192 (decode), 4608 (encode); 0 = never. */
 enum { ZPK_OPT_LZ4_TWO_STAGE_MIN = 2, ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP = 3, ZPK_OPT_ENC_SPLIT_MIN = 6, ZPK_OPT_DEC_SPLIT_MIN = 7, ZPK_OPT_ORDER_MIN = 8,
        ZPK_OPT_LZ4_EXEC_WINDOW = 5 /* stage 2 of the two-stage path: 1 = output assembled in an LDS window, 0 = in the output slot */,
        ZPK_OPT_DEV_LZ4_EXEC_PAD = 4 /* measurement aid: bytes of idle LDS per stage-2 workgroup, i.e. fewer entries in flight per CU */ };

@@ -678,6 +678,7 @@ struct zpk_codec {
     u8*  d_packed = nullptr;     u64 packed_cap = 0;   // host encode path: packed payload stream
     u8*  d_packoff = nullptr;    u64 packoff_cap = 0;  // host encode path: payload offsets
     u8*  d_xpart = nullptr;      u64 xpart_cap = 0;    // host encode path, split entries: span list | 64 bytes of XXH3 partial sums per 1 KiB block | hashes
+    u64  enc_order_min = 4608;                         // ... and encode batches their ticket queue (the encoder's resident waves: 18 per CU)
     u64  order_min = 8192;                             // ZPK_OPT_ORDER_MIN: decode batches of at least this many entries run their work lists largest entries first
     u64  dec_split_min = ZPK_DEC_SPLIT_MIN_DEFAULT;    // ZPK_OPT_DEC_SPLIT_MIN: entries of at least this many bytes that ARE sequences of frames are decoded frame-parallel
     u32  big_last[2] = {0, 0};                         // host decode path, most recent call: entries decoded frame-parallel, their frames
@@ -1730,7 +1731,7 @@ int zpk_codec_set_option(zpk_codec* c, int option, int value)
     if (option == ZPK_OPT_LZ4_TWO_STAGE_MIN) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_min = (u32)value; return ZPK_OK; }
     if (option == ZPK_OPT_LZ4_EXEC_WINDOW) { c->lz4_exec_window = value ? 1 : 0; return ZPK_OK; }
     if (option == ZPK_OPT_DEV_LZ4_EXEC_PAD) { if (value < 0 || value > (120 << 10)) return ZPK_E_INVALID; c->lz4_exec_pad = (u32)value; return ZPK_OK; }
-    if (option == ZPK_OPT_ORDER_MIN) { if (value < 0) return ZPK_E_INVALID; c->order_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
+    if (option == ZPK_OPT_ORDER_MIN) { if (value < 0) return ZPK_E_INVALID; c->order_min = c->enc_order_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_DEC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->dec_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_ENC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->enc_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_max_comp = (u32)value; return ZPK_OK; }
