@@ -6,6 +6,8 @@
 #   c: host-pointer rates (read and write path), C5 (bench, trace at 12 500 entries, PMC), encode rate per class at levels 1 and 3
 #   d: fuzz (damaged frames, LZ4 + Zstandard)
 #   e: the LZ4 two-stage A/B of round 4 (one-kernel path / stage 2 over the output slot / stage 2 with the LDS window), stream rates
+#   f: soak of the streaming write / read pair (600 random sizes, chunkings and windows)
+#   g: scheduling and large entries (round 4): work lists largest first A/B (C4, C2, C3), ragged encode batch A/B, one 256 MiB entry
 # Everything lands under gpurun_out/<tag>/; the PMC summaries are also copied to profiles/<tag>/ ON THE BOX so that the bench lines quote them.
 part=${1:-a}; tag=${2:-r04}
 out=gpurun_out/$tag
@@ -46,6 +48,10 @@ d)
   timeout -k 10 1100 python3 tools/fuzz_gpu.py 400 11 all > $out/${tag}_fuzz_all.log 2>&1; echo "fuzz rc=$?"; tail -8 $out/${tag}_fuzz_all.log ;;
 e)
   tools/r4_ab.sh $tag skip-tests 2>&1 | tee $out/${tag}_lz4_two_stage_ab.txt ;;
+g)
+  tools/r4_order.sh 2>&1 | tee $out/${tag}_order_ab.txt
+  timeout -k 10 600 python3 tools/enc_ragged.py 30000 1 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_enc_ragged_order.txt
+  timeout -k 10 400 python3 tools/big_entry_rate.py 256 16 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_entry_rate.txt ;;
 f)
   # soak of the streaming write / read pair: random entry sizes, chunkings and windows (the suite runs 30 of these; here 600 more, other seed)
   ZPK_STREAM_FUZZ_ITERS=600 ZPK_STREAM_FUZZ_SEED=7 timeout -k 10 1000 python -m pytest tests/test_gpu_zpack_api.py -x -q -m gpu -k random_sizes_and_windows > $out/${tag}_stream_soak.log 2>&1; echo "stream soak rc=$?" | tee -a $out/${tag}_stream_soak.log; tail -4 $out/${tag}_stream_soak.log ;;
