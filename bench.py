@@ -283,6 +283,8 @@ def main():
         codec.set_option(zpack_amd.OPT_LZ4_TWO_STAGE_MIN, 0x7FFFFFFF if os.environ["ZPK_BENCH_LZ4_TWO"] == "never" else 0)
     if os.environ.get("ZPK_BENCH_ORDER_MIN"):                               # A/B: work lists largest entries first (0 = never)
         codec.set_option(zpack_amd.OPT_ORDER_MIN, int(os.environ["ZPK_BENCH_ORDER_MIN"]))
+    if os.environ.get("ZPK_BENCH_ORDER_FAST"):
+        codec.set_option(zpack_amd.OPT_ORDER_FAST_LAST, int(os.environ["ZPK_BENCH_ORDER_FAST"]))
     if os.environ.get("ZPK_BENCH_LZ4_EXEC_WINDOW"):
         codec.set_option(5, int(os.environ["ZPK_BENCH_LZ4_EXEC_WINDOW"]))
     if os.environ.get("ZPK_BENCH_LZ4_EXEC_PAD"):                            # measurement aid: fewer LZ4 entries in flight per CU

@@ -135,7 +135,7 @@ int         zpk_codec_device(const zpk_codec* c);
  *                                   FIRST (size classes by powers of two; a device counting sort behind the classification): one
  *                                   wave works on one entry, so a large entry that starts last runs on alone; encode batches order
  *                                   their ticket queue the same way.  Default 8192 (decode), 4608 (encode); 0 = never. */
-enum { ZPK_OPT_LZ4_TWO_STAGE_MIN = 2, ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP = 3, ZPK_OPT_ENC_SPLIT_MIN = 6, ZPK_OPT_DEC_SPLIT_MIN = 7, ZPK_OPT_ORDER_MIN = 8,
+enum { ZPK_OPT_LZ4_TWO_STAGE_MIN = 2, ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP = 3, ZPK_OPT_ENC_SPLIT_MIN = 6, ZPK_OPT_DEC_SPLIT_MIN = 7, ZPK_OPT_ORDER_MIN = 8, ZPK_OPT_ORDER_FAST_LAST = 9 /* a batch of ONE size class runs the entries that did not compress (a copy to decode) last: 1 (default) / 0 */,
        ZPK_OPT_LZ4_EXEC_WINDOW = 5 /* stage 2 of the two-stage path: 1 = output assembled in an LDS window, 0 = in the output slot */,
        ZPK_OPT_DEV_LZ4_EXEC_PAD = 4 /* measurement aid: bytes of idle LDS per stage-2 workgroup, i.e. fewer entries in flight per CU */ };
 int         zpk_codec_set_option(zpk_codec* c, int option, int value);

@@ -504,14 +504,16 @@ def test_stream_steps_agree_with_one_shot_on_foreign_and_damaged_frames(codec, g
             assert got == outs[0][:min(produced, usize)].tobytes(), label
 
 
-def test_work_lists_largest_first_give_identical_results(codec):
-    """A ragged batch (200 B ... 300 KiB, both methods + damaged and refused entries) decoded with its work lists in archive order and
+@pytest.mark.parametrize("lo,hi", [(200, 300000), (3000, 3000)])
+def test_work_lists_largest_first_give_identical_results(codec, lo, hi):
+    """A ragged batch (200 B ... 300 KiB; and a batch of ONE size, which is ordered by "did it compress" instead: both methods, all four
+    classes, + damaged and refused entries) decoded with its work lists in archive order and
     largest entries first (ZPK_OPT_ORDER_MIN: the device counting sort behind the classification): identical statuses, hashes, produced
     counts and bytes; and every entry is on exactly one list position (nothing lost, nothing twice — the output of a skipped entry
     would stay zero)."""
     import torch
     n = 6000
-    b = dg.Batch(n, 200, 300000, method=dg.COIN, level=3, seed=21)
+    b = dg.Batch(n, lo, hi, method=dg.COIN, level=3, seed=21)
     desc, total = zpack_amd.decode_descs_from_batch(b)
     desc = desc.copy()
     arc = b.archive.copy()
@@ -528,6 +530,7 @@ def test_work_lists_largest_first_give_identical_results(codec):
         codec.set_option(zpack_amd.OPT_ORDER_MIN, order_min)
         dst = torch.zeros(total, dtype=torch.uint8, device=dev)
         dres = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()                     # (the fills above run on torch's stream, the batch on the codec's own)
         codec.decode_batch_device(src, ddesc, n, dst, dres)
         torch.cuda.synchronize()
         got.append((dres.cpu().numpy().view(zpack_amd.DECODE_RESULT).copy(), dst.cpu().numpy().copy()))

@@ -18,7 +18,7 @@ METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
 DF_GENERAL = 2
 K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_LZ4_PARSE, K_ENCODE = 0, 1, 2, 3, 4, 5, 6, 7
-OPT_LZ4_TWO_STAGE_MIN, OPT_LZ4_TWO_STAGE_MAX_COMP, OPT_DEV_LZ4_EXEC_PAD, OPT_LZ4_EXEC_WINDOW, OPT_ENC_SPLIT_MIN, OPT_DEC_SPLIT_MIN, OPT_ORDER_MIN = 2, 3, 4, 5, 6, 7, 8      # zpk_codec_set_option (include/zpack_codec.h)
+OPT_LZ4_TWO_STAGE_MIN, OPT_LZ4_TWO_STAGE_MAX_COMP, OPT_DEV_LZ4_EXEC_PAD, OPT_LZ4_EXEC_WINDOW, OPT_ENC_SPLIT_MIN, OPT_DEC_SPLIT_MIN, OPT_ORDER_MIN, OPT_ORDER_FAST_LAST = 2, 3, 4, 5, 6, 7, 8, 9      # zpk_codec_set_option (include/zpack_codec.h)
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
 DECODE_DESC = np.dtype([("src_offset", "<u8"), ("comp_size", "<u8"), ("uncomp_size", "<u8"), ("expect_hash", "<u8"),
@@ -107,13 +107,25 @@ class Codec:
             raise RuntimeError("%s failed (%d): %s" % (what, rc, self.L.zpk_codec_last_error(self.h).decode()))
 
     # ---- device-resident batch (torch uint8 CUDA tensors) ----
+    # stream=None runs the batch on the codec's OWN stream, which is not ordered with torch's: fills / copies torch has enqueued on its
+    # current stream for these tensors (a torch.zeros of the result array ...) must have finished before the codec touches them.
+    @staticmethod
+    def _settle(stream):
+        if not stream:
+            import sys
+            t = sys.modules.get("torch")
+            if t is not None and t.cuda.is_available() and t.cuda.is_initialized():
+                t.cuda.current_stream().synchronize()
+
     def decode_batch_device(self, src, desc_dev, n, dst, results_dev, stream=None):
+        self._settle(stream)
         st = C.c_void_p(stream) if stream else None
         self._chk(self.L.zpk_codec_decode_batch_device(self.h, src.data_ptr(), src.numel(), desc_dev.data_ptr(), n,
                                                        dst.data_ptr(), dst.numel(), results_dev.data_ptr(), st),
                   "zpk_codec_decode_batch_device")
 
     def encode_batch_device(self, src, desc_dev, n, dst, results_dev, stream=None):
+        self._settle(stream)
         st = C.c_void_p(stream) if stream else None
         self._chk(self.L.zpk_codec_encode_batch_device(self.h, src.data_ptr(), src.numel(), desc_dev.data_ptr(), n,
                                                        dst.data_ptr(), dst.numel(), results_dev.data_ptr(), st),
@@ -121,6 +133,7 @@ class Codec:
 
     def pack_batch_device(self, slots, desc_dev, results_dev, n, packed, offsets_dev, max_entry_size, stream=None):
         """offsets_dev: int64 CUDA tensor of n + 1; packed: uint8 CUDA tensor or None (sizes only)."""
+        self._settle(stream)
         st = C.c_void_p(stream) if stream else None
         self._chk(self.L.zpk_codec_pack_batch_device(self.h, slots.data_ptr(), desc_dev.data_ptr(), results_dev.data_ptr(), n,
                                                      packed.data_ptr() if packed is not None else None,
@@ -128,6 +141,7 @@ class Codec:
                                                      max_entry_size, st), "zpk_codec_pack_batch_device")
 
     def hash_batch_device(self, src, offsets_dev, sizes_dev, n, hashes_dev, stream=None):
+        self._settle(stream)
         st = C.c_void_p(stream) if stream else None
         self._chk(self.L.zpk_codec_hash_batch_device(self.h, src.data_ptr(), offsets_dev.data_ptr(), sizes_dev.data_ptr(),
                                                      n, hashes_dev.data_ptr(), st), "zpk_codec_hash_batch_device")

@@ -47,7 +47,7 @@ enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT =
        C_LZ4_TWO_OK = 23,                       // entries finished by the two-stage path
        C_LZ4_BUMP = 24,                         // (two words, 8-byte aligned) record-arena allocator of k_lz4_parse
        C_ORDER_SPAN = 26,                       // (two words) largest size class and largest 15 - class among the Zstandard / LZ4 entries
-       C_ORDER = 32,                            // k_order_*: [2 lists][16 size classes] entry counts, then the same again as fill cursors
+       C_ORDER = 32,                            // k_order_*: [2 lists][16 classes] entry counts, then the same again as fill cursors
        N_COUNTERS = 32 + 64 };
 enum { N_LISTS_ALLOC = N_LISTS + 5 };           // + the two retry lists + what the two-stage LZ4 path leaves to the general decoder + the two ordered lists
 
@@ -60,6 +60,11 @@ __device__ __forceinline__ int order_class(u64 size)
     const int b = 26 - lg;                                                            // >= 64 MiB: class 0 ... < 4 KiB: class 15
     return b < 0 ? 0 : (b > ORD_CLASSES - 1 ? ORD_CLASSES - 1 : b);
 }
+// A batch of ONE size class (the uniform workloads) has nothing to order by size; there the entries that did not compress — payload not
+// smaller than ~15/16 of the size: stored LZ4 blocks, raw Zstandard blocks, a copy that decodes several times faster than anything
+// compressed — go LAST: they are what is left to fill the final round with (C2: +0.75 % over six A/B pairs; on the ragged c4_mixed the
+// same key inside every size class measured -4 % +- noise, so it is not used there).
+__device__ __forceinline__ int order_fast(u64 size, u64 comp) { return comp * 16 >= size * 15 ? 1 : 0; }
 __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restrict__ desc, u64 n, u64 src_size, u64 dst_size,
                                                   zpk_decode_result* __restrict__ res, u32* __restrict__ lists, u64 list_stride,
                                                   u32* __restrict__ counters)
@@ -131,17 +136,19 @@ __device__ __forceinline__ void order_wave_rank(int b, int lane, u32& rank, u32&
     }
 }
 __global__ __launch_bounds__(256) void k_order_count(const zpk_decode_desc* __restrict__ desc, const u32* __restrict__ lists, u64 list_stride,
-                                                     u32* __restrict__ counters)
+                                                     u32* __restrict__ counters, int fast_last)
 {
     __shared__ u32 h[ORD_CLASSES];
     const int L = blockIdx.y == 0 ? L_ZSTD : L_LZ4;
     const u32 cnt = counters[L];
-    if ((u64)blockIdx.x * 256 >= cnt || order_single_class(counters)) return;
+    const bool uniform = order_single_class(counters);
+    if ((u64)blockIdx.x * 256 >= cnt || (uniform && !fast_last)) return;
     if (threadIdx.x < ORD_CLASSES) h[threadIdx.x] = 0;
     __syncthreads();
     const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = lane_id();
-    const int b = k < cnt ? order_class(desc[lists[(u64)L * list_stride + k]].uncomp_size) : -1;
+    int b = -1;
+    if (k < cnt) { const zpk_decode_desc& d = desc[lists[(u64)L * list_stride + k]]; b = uniform ? order_fast(d.uncomp_size, d.comp_size) : order_class(d.uncomp_size); }
     u32 rank, count;
     order_wave_rank(b, lane, rank, count);
     if (b >= 0 && rank == 0) atomicAdd(&h[b], count);
@@ -149,19 +156,20 @@ __global__ __launch_bounds__(256) void k_order_count(const zpk_decode_desc* __re
     if (threadIdx.x < ORD_CLASSES && h[threadIdx.x]) atomicAdd(&counters[C_ORDER + blockIdx.y * ORD_CLASSES + threadIdx.x], h[threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void k_order_fill(const zpk_decode_desc* __restrict__ desc, const u32* __restrict__ lists, u64 list_stride,
-                                                    u32* __restrict__ ordered /* two lists of list_stride */, u32* __restrict__ counters)
+                                                    u32* __restrict__ ordered /* two lists of list_stride */, u32* __restrict__ counters, int fast_last)
 {
     __shared__ u32 wcount[4][ORD_CLASSES], base[ORD_CLASSES];
     const int L = blockIdx.y == 0 ? L_ZSTD : L_LZ4;
     const u32 cnt = counters[L];
     if ((u64)blockIdx.x * 256 >= cnt) return;
     const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (order_single_class(counters)) { if (k < cnt) ordered[(u64)blockIdx.y * list_stride + k] = lists[(u64)L * list_stride + k]; return; }
+    const bool uniform = order_single_class(counters);
+    if (uniform && !fast_last) { if (k < cnt) ordered[(u64)blockIdx.y * list_stride + k] = lists[(u64)L * list_stride + k]; return; }
     if (threadIdx.x < 4 * ORD_CLASSES) (&wcount[0][0])[threadIdx.x] = 0;
     __syncthreads();
     const int lane = lane_id(), w = threadIdx.x >> 6;
     u32 e = 0; int b = -1;
-    if (k < cnt) { e = lists[(u64)L * list_stride + k]; b = order_class(desc[e].uncomp_size); }
+    if (k < cnt) { e = lists[(u64)L * list_stride + k]; b = uniform ? order_fast(desc[e].uncomp_size, desc[e].comp_size) : order_class(desc[e].uncomp_size); }
     u32 rank, count;
     order_wave_rank(b, lane, rank, count);
     if (b >= 0 && rank == 0) wcount[w][b] = count;
@@ -679,6 +687,7 @@ struct zpk_codec {
     u8*  d_packoff = nullptr;    u64 packoff_cap = 0;  // host encode path: payload offsets
     u8*  d_xpart = nullptr;      u64 xpart_cap = 0;    // host encode path, split entries: span list | 64 bytes of XXH3 partial sums per 1 KiB block | hashes
     u64  enc_order_min = 4608;                         // ... and encode batches their ticket queue (the encoder's resident waves: 18 per CU)
+    int  order_fast_last = 1;                          // ZPK_OPT_ORDER_FAST_LAST: a batch of one size class runs its incompressible entries last
     u64  order_min = 8192;                             // ZPK_OPT_ORDER_MIN: decode batches of at least this many entries run their work lists largest entries first
     u64  dec_split_min = ZPK_DEC_SPLIT_MIN_DEFAULT;    // ZPK_OPT_DEC_SPLIT_MIN: entries of at least this many bytes that ARE sequences of frames are decoded frame-parallel
     u32  big_last[2] = {0, 0};                         // host decode path, most recent call: entries decoded frame-parallel, their frames
@@ -892,8 +901,8 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     if (n >= c->order_min) {
         u32* const ordered = c->d_lists + (u64)(N_LISTS + 3) * stride;
         const dim3 og((u32)((n + 255) / 256), 2);
-        hipLaunchKernelGGL(k_order_count, og, dim3(256), 0, st, desc, (const u32*)c->d_lists, stride, c->d_counters);
-        hipLaunchKernelGGL(k_order_fill, og, dim3(256), 0, st, desc, (const u32*)c->d_lists, stride, ordered, c->d_counters);
+        hipLaunchKernelGGL(k_order_count, og, dim3(256), 0, st, desc, (const u32*)c->d_lists, stride, c->d_counters, c->order_fast_last);
+        hipLaunchKernelGGL(k_order_fill, og, dim3(256), 0, st, desc, (const u32*)c->d_lists, stride, ordered, c->d_counters, c->order_fast_last);
         zstd_list = ordered; lz4_list = ordered + stride;
     }
     ZPK_KEV(ZPK_K_CLASSIFY, 1);
@@ -1731,6 +1740,7 @@ int zpk_codec_set_option(zpk_codec* c, int option, int value)
     if (option == ZPK_OPT_LZ4_TWO_STAGE_MIN) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_min = (u32)value; return ZPK_OK; }
     if (option == ZPK_OPT_LZ4_EXEC_WINDOW) { c->lz4_exec_window = value ? 1 : 0; return ZPK_OK; }
     if (option == ZPK_OPT_DEV_LZ4_EXEC_PAD) { if (value < 0 || value > (120 << 10)) return ZPK_E_INVALID; c->lz4_exec_pad = (u32)value; return ZPK_OK; }
+    if (option == ZPK_OPT_ORDER_FAST_LAST) { c->order_fast_last = value ? 1 : 0; return ZPK_OK; }
     if (option == ZPK_OPT_ORDER_MIN) { if (value < 0) return ZPK_E_INVALID; c->order_min = c->enc_order_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_DEC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->dec_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_ENC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->enc_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
