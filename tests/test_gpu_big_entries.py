@@ -4,6 +4,7 @@ and the host read path decodes an entry that is such a sequence with one wave pe
 verdicts are those of the one-wave paths, of the oracle and of the compiled reference (whose readers continue with the next frame:
 lib/zpack_read.c:380, :414-439)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -123,7 +124,7 @@ def test_big_entry_damage_gets_the_one_wave_verdict(codec):
         good = pay[0].copy()
         h = int(res["hash"][0])
         variants = []
-        for k in range(10):                                                            # a flipped byte somewhere in the payload
+        for k in range(int(os.environ.get("ZPK_BIG_FUZZ_ITERS", "10"))):                   # a flipped byte somewhere in the payload (a soak: tools/evidence.sh f)
             b = good.copy(); at = int(rng.integers(0, len(b))); b[at] ^= 0x41
             variants.append(("flip@%d" % at, b, len(b), h, len(plain)))
         b = good.copy(); b[4] ^= 0x08
@@ -151,8 +152,9 @@ def test_big_entry_damage_gets_the_one_wave_verdict(codec):
                 assert par == 1 and r1["status"][0] == 0
             if label == "hash":
                 assert par == 1 and r1["status"][0] == 15 and np.array_equal(out1[0][:len(plain)], plain), key    # the bytes stay, like the reference's
-            rc, out, got, hh = o.entry_decode(arc.tobytes(), int(offs[0]), csize, len(plain), eh, method, cap)
-            assert rc == int(r1["status"][0]), (key, rc, r1)
+            if not label.startswith("flip") or int(label[5:]) % 7 == 0 or len(variants) < 40:
+                rc, out, got, hh = o.entry_decode(arc.tobytes(), int(offs[0]), csize, len(plain), eh, method, cap)
+                assert rc == int(r1["status"][0]), (key, rc, r1)
     codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
 
 

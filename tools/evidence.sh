@@ -54,5 +54,6 @@ g)
   timeout -k 10 400 python3 tools/big_entry_rate.py 256 16 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_entry_rate.txt ;;
 f)
   # soak of the streaming write / read pair: random entry sizes, chunkings and windows (the suite runs 30 of these; here 600 more, other seed)
-  ZPK_STREAM_FUZZ_ITERS=600 ZPK_STREAM_FUZZ_SEED=7 timeout -k 10 1000 python -m pytest tests/test_gpu_zpack_api.py -x -q -m gpu -k random_sizes_and_windows > $out/${tag}_stream_soak.log 2>&1; echo "stream soak rc=$?" | tee -a $out/${tag}_stream_soak.log; tail -4 $out/${tag}_stream_soak.log ;;
+  ZPK_STREAM_FUZZ_ITERS=600 ZPK_STREAM_FUZZ_SEED=7 timeout -k 10 1000 python -m pytest tests/test_gpu_zpack_api.py -x -q -m gpu -k random_sizes_and_windows > $out/${tag}_stream_soak.log 2>&1; echo "stream soak rc=$?" | tee -a $out/${tag}_stream_soak.log; tail -4 $out/${tag}_stream_soak.log
+  ZPK_BIG_FUZZ_ITERS=250 timeout -k 10 1000 python -m pytest tests/test_gpu_big_entries.py -x -q -m gpu -k damage > $out/${tag}_big_entry_damage_soak.log 2>&1; echo "big-entry damage soak (3 x 250 flipped bytes: frame-parallel verdict == one-wave verdict) rc=$?" | tee -a $out/${tag}_big_entry_damage_soak.log; tail -3 $out/${tag}_big_entry_damage_soak.log ;;
 esac
