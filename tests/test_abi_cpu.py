@@ -119,3 +119,19 @@ def test_product_never_touches_the_oracle():
     assert bad == []
     so_deps = subprocess.check_output(["ldd", zpack_amd.ZPACK_SO]).decode()
     assert "oracle" not in so_deps and "zpack_ref" not in so_deps
+
+
+def test_option_numbers_of_the_python_view_match_the_header():
+    """zpk_codec_set_option's option numbers (include/zpack_codec.h) and the flag bits the descriptors carry are what the Python
+    view passes; an unknown option must stay an error (ZPK_E_INVALID) on a library without a device as well."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "zpack_codec.h")).read()
+    nums = {m.group(1): int(m.group(2)) for m in re.finditer(r"(ZPK_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
+    view = {"ZPK_OPT_LZ4_TWO_STAGE_MIN": zpack_amd.OPT_LZ4_TWO_STAGE_MIN, "ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP": zpack_amd.OPT_LZ4_TWO_STAGE_MAX_COMP,
+            "ZPK_OPT_DEV_LZ4_EXEC_PAD": zpack_amd.OPT_DEV_LZ4_EXEC_PAD, "ZPK_OPT_LZ4_EXEC_WINDOW": zpack_amd.OPT_LZ4_EXEC_WINDOW,
+            "ZPK_OPT_ENC_SPLIT_MIN": zpack_amd.OPT_ENC_SPLIT_MIN, "ZPK_OPT_DEC_SPLIT_MIN": zpack_amd.OPT_DEC_SPLIT_MIN,
+            "ZPK_OPT_ORDER_MIN": zpack_amd.OPT_ORDER_MIN, "ZPK_OPT_ORDER_FAST_LAST": zpack_amd.OPT_ORDER_FAST_LAST}
+    assert nums == view, (nums, view)
+    assert len(set(nums.values())) == len(nums)
+    assert re.search(r"#define\s+ZPK_EF_PIECE\s+0x80000000u", hdr) and re.search(r"#define\s+ZPK_DF_SKIP_HASH\s+1u", hdr)
+    assert zpack_amd.DF_SKIP_HASH == 1
