@@ -201,7 +201,7 @@ def _lz4f_custom(data, block_id=0, block_indep=0, content_cksum=0, block_cksum=0
     return out.raw[:n]
 
 
-def _zstd_custom(data, level=3, checksum=0, content_size=1, window_log=0, flush_every=0):
+def _zstd_custom(data, level=3, checksum=0, content_size=1, window_log=0, flush_every=0, pledged=False):
     z = C.CDLL("/opt/conda/lib/libzstd.so.1")
     z.ZSTD_createCCtx.restype = C.c_void_p
     z.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -218,6 +218,10 @@ def _zstd_custom(data, level=3, checksum=0, content_size=1, window_log=0, flush_
     z.ZSTD_CCtx_setParameter(cctx, 200, content_size)    # ZSTD_c_contentSizeFlag
     if window_log:
         z.ZSTD_CCtx_setParameter(cctx, 101, window_log)  # ZSTD_c_windowLog
+    if pledged:                                          # the frame header then carries Frame_Content_Size
+        z.ZSTD_CCtx_setPledgedSrcSize.argtypes = [C.c_void_p, C.c_ulonglong]
+        z.ZSTD_CCtx_setPledgedSrcSize.restype = C.c_size_t
+        assert z.ZSTD_CCtx_setPledgedSrcSize(cctx, len(data)) < (1 << 62)
     cap = len(data) + len(data) // 8 + 4096
     out = C.create_string_buffer(cap)
     ob = Buf(C.cast(out, C.c_void_p), cap, 0)
@@ -323,6 +327,33 @@ def foreign_frames():
     add("lz4f:bad_bd_header_cut_short", 2, bytes(f[:10]), text)
     g = bytearray(_lz4f_custom(text, content_size=1)); g[4] |= 0x02      # the reserved FLG bit
     add("lz4f:bad_flg_header_cut_short", 2, bytes(g[:10]), text)
+
+    # round 4, late: sequences of frames that each state their content size, outputs on 256-byte boundaries — what this library's writers
+    # emit for large / streamed entries and what its host reader decodes one wave per FRAME.  The verdicts below are the reference's.
+    import xxhash
+    cuts = [0, 4096, 4096 + 6144, 12000]
+    zf = [_zstd_custom(text[a:b], level=(3, 1, 5)[k], checksum=(k == 2), pledged=True) for k, (a, b) in enumerate(zip(cuts, cuts[1:]))]
+    lf = [_lz4f_custom(text[a:b], content_size=1, content_cksum=(k == 1), block_cksum=(k == 2)) for k, (a, b) in enumerate(zip(cuts, cuts[1:]))]
+    add("zstd:three_frames_with_sizes", 1, b"".join(zf), text)
+    add("lz4f:three_frames_with_sizes", 2, b"".join(lf), text)
+    for name, fs, m in (("zstd", zf, 1), ("lz4f", lf, 2)):
+        mid = bytearray(fs[1]); mid[len(mid) // 2] ^= 0x10
+        add(name + ":three_frames_middle_damaged", m, fs[0] + bytes(mid) + fs[2], text)
+        add(name + ":three_frames_last_cut", m, fs[0] + fs[1] + fs[2][:-6], text)
+        add(name + ":three_frames_then_garbage", m, b"".join(fs) + b"\x01\x02\x03\x04\x05\x06\x07\x08\x09", text, max_size=len(text) + 64)
+        add(name + ":three_frames_capacity_short", m, b"".join(fs), text, max_size=len(text) - 1)
+        add(name + ":three_frames_sizes_add_up_to_less", m, fs[0] + fs[1], text)
+        add(name + ":three_frames_wrong_order", m, fs[1] + fs[0] + fs[2], text)
+    lie = bytearray(lf[1]); lie[6:14] = struct.pack("<Q", 6144 + 256)                 # the content size field lies; header checksum left as it was
+    add("lz4f:three_frames_size_field_changed", 2, lf[0] + bytes(lie) + lf[2], text)
+    lie[14] = (xxhash.xxh32(bytes(lie[4:14]), seed=0).intdigest() >> 8) & 0xFF        # ... and with a header checksum that agrees with the lie
+    add("lz4f:three_frames_size_field_lies_consistently", 2, lf[0] + bytes(lie) + lf[2], text, max_size=len(text) + 256)
+    zl = bytearray(zf[1])                                                             # zstd: the 2-byte FCS (6144 - 256) changed to claim 256 bytes more
+    fcs_at = 5 + (0 if zl[4] & 0x20 else 1)
+    if zl[4] >> 6 == 1: zl[fcs_at:fcs_at + 2] = struct.pack("<H", 6144 - 256 + 256)
+    elif zl[4] >> 6 == 2: zl[fcs_at:fcs_at + 4] = struct.pack("<I", 6144 + 256)
+    else: raise RuntimeError("unexpected frame header %02x" % zl[4])
+    add("zstd:three_frames_size_field_lies", 1, zf[0] + bytes(zl) + zf[2], text, max_size=len(text) + 256)
     return cases
 
 

@@ -126,15 +126,23 @@ def test_status_codes_match_reference(codec, golden_dir):
             assert dg.xxh3(outs[0]) == c["out_xxh3"], c["label"]
 
 
-def test_foreign_frames_match_reference(codec, golden_dir):
+@pytest.mark.parametrize("split_min", [2 << 20, 1])
+def test_foreign_frames_match_reference(codec, golden_dir, split_min):
+    """split_min = 1: every entry that IS a sequence of frames with content sizes on 256-byte output boundaries is decoded one wave
+    per frame (ZPK_OPT_DEC_SPLIT_MIN) — the reference's verdicts and bytes must not depend on that."""
+    codec.set_option(zpack_amd.OPT_DEC_SPLIT_MIN, split_min)
+    parallel = 0
     for c in _load(golden_dir, "foreign_frames.json"):
         fr = bytes.fromhex(c["frame"])
         e = dict(offset=10, comp_size=len(fr), uncomp_size=c["uncomp_size"], hash=c["hash"], method=c["method"])
         arc = zpk.assemble([fr], [("f", 10, len(fr), c["uncomp_size"], c["hash"], c["method"])])
         res, outs = codec.decode_batch_host(arc, _desc([e], [c["max_size"]]))
+        parallel += codec.decode_stats()["frame_parallel_entries"]
         assert int(res[0]["status"]) == c["rc"], (c["label"], res[0])
         if c["rc"] == 0:
             assert dg.xxh3(outs[0][:c["uncomp_size"]]) == c["plain_xxh3"], c["label"]
+    codec.set_option(zpack_amd.OPT_DEC_SPLIT_MIN, 2 << 20)
+    assert split_min != 2 << 20 or parallel == 0
 
 
 @pytest.mark.parametrize("method,level,size,n", [(dg.LZ4, 0, 65536, 512), (dg.ZSTD, 3, 262144, 96), (dg.NONE, 0, 65536, 256),

@@ -1041,6 +1041,34 @@ int zpk_codec_decode_batch_device(zpk_codec* c, const uint8_t* src, uint64_t src
     return decode_launch(c, src, src_size, src, src + src_size, desc, n, dst, dst_size, results, st);
 }
 
+// An entry whose frames end before uncomp_size bytes exist (a short decode is not an error of the libraries): lib/zpack_read.c:466
+// hashes buffer[0, uncomp_size) all the same — the decoded bytes followed by whatever the CALLER'S buffer held.  The device slot holds
+// something else there (an earlier batch's output), so for these rare entries the caller's bytes are brought up behind the decoded
+// ones and the slot is hashed again: the verdict is the one the reference reaches on this caller's buffer.
+static int rehash_short_entries(zpk_codec* c, const zpk_decode_desc* hd, const zpk_decode_desc* desc, u64 n, uint8_t* const* dst_ptrs,
+                                zpk_decode_result* results)
+{
+    for (u64 i = 0; i < n; i++) {
+        zpk_decode_result& r = results[i];
+        if ((r.status != 0 && r.status != 15) || r.produced >= desc[i].uncomp_size || desc[i].uncomp_size > desc[i].dst_capacity ||
+            desc[i].comp_size == 0 /* :328: OK before anything is read */ || desc[i].method == ZPK_METHOD_NONE) continue;
+        int rc;
+        if ((rc = grow(c, (void**)&c->d_xpart, &c->xpart_cap, 64))) return rc;
+        const u64 tail = desc[i].uncomp_size - r.produced;
+        u64 meta[3] = { hd[i].dst_offset, desc[i].uncomp_size, 0 };
+        HIPCHK(c, hipMemcpyAsync(c->d_dst + hd[i].dst_offset + r.produced, dst_ptrs[i] + r.produced, tail, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_xpart, meta, sizeof(meta), hipMemcpyHostToDevice, c->stream));
+        u64* m = (u64*)c->d_xpart;
+        hipLaunchKernelGGL(k_hash, dim3(1), dim3(64), 0, c->stream, (const u8*)c->d_dst, (const u64*)m, (const u64*)(m + 1), (u64)1, m + 2);
+        u64 h = 0;
+        HIPCHK(c, hipMemcpyAsync(&h, m + 2, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        r.hash = h;
+        r.status = (h == desc[i].expect_hash || (desc[i].flags & ZPK_DF_SKIP_HASH)) ? 0 : 15;
+    }
+    return ZPK_OK;
+}
+
 // One sub-batch of the host path: entries [0, n) of hd/desc, whose slots (hd[i].dst_offset, already laid out) total
 // out_total bytes.  `image` is what gets staged: either the archive itself (span mode, src_offset = archive offsets,
 // staged range [lo, hi)) or a packed copy of just these payloads (gather mode: hd[i].src_offset already rewritten).
@@ -1217,7 +1245,7 @@ static int decode_host_chunk(zpk_codec* c, const u8* image, u64 image_size, u64 
             if (results[i].produced) e = hipMemcpy(dst_ptrs[i], c->d_dst + hd[i].dst_offset, results[i].produced, hipMemcpyDeviceToHost);
     }
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "D2H: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
-    return ZPK_OK;
+    return rehash_short_entries(c, hd, desc, n, dst_ptrs, results);
 }
 
 // ---- the same chunk as a three-stage pipeline (round 3) ------------------------------------------------------------------------
@@ -1346,6 +1374,7 @@ static int decode_host_pipelined(zpk_codec* c, const u8* image, u64 image_size, 
         for (int k = 0; k < np; k++) for (int w = 0; w < N_COUNTERS; w++) c->host_totals[w] += c->piece_counters[k][w];
         c->totals_valid = 1;
     }
+    if (rc == ZPK_OK) rc = rehash_short_entries(c, hd, desc, n, dst_ptrs, results);
     return rc;
 }
 
