@@ -167,6 +167,18 @@ def status_cases():
                     add("%s:flip_%s_%02x" % (mname, pos_name, bit), arc, 0, n0, flips=[(e0["offset"] + pos, bit)])
         else:
             add(mname + ":uncomp_gt_comp", arc, 0, n0 + 10, dict(uncomp_size=n0 + 1))
+    # round 4, late: an entry whose size field and hash agree with each other but not with the frame — :466 hashes buffer[0, uncomp_size),
+    # whatever the decoder produced: a prefix of a longer output, or the output followed by what the caller's buffer held (zeros here)
+    for mname, method, level in (("none", 0, 0), ("lz4", 2, 0), ("zstd", 1, 3)):
+        arc = R.write_archive([("a", text), ("b", big[:70000] if method != 0 else text[:100])], method, level)
+        n0 = len(text)
+        add(mname + ":size_and_hash_of_a_prefix", arc, 0, n0, dict(uncomp_size=n0 - 10, hash=dg.xxh3(text[:n0 - 10])))
+        add(mname + ":size_and_hash_of_a_prefix_exact_buffer", arc, 0, n0 - 10, dict(uncomp_size=n0 - 10, hash=dg.xxh3(text[:n0 - 10])))
+        add(mname + ":size_and_hash_with_zero_tail", arc, 0, n0 + 50, dict(uncomp_size=n0 + 10, hash=dg.xxh3(text + bytes(10))))
+        if method != 0:
+            add(mname + ":multi_size_and_hash_of_a_prefix", arc, 1, 70000, dict(uncomp_size=66000, hash=dg.xxh3(big[:66000])))
+            # (no zero-tail case for the large entry: libzstd's wide copies leave bytes of their own just behind a long output — the
+            # reference returns FILE_HASH_MISMATCH there through an accident of the library, not through anything zpack does)
     return dict(bases=bases, cases=cases)
 
 
