@@ -46,6 +46,7 @@ enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT =
        C_LZ4_LEFT = 21, C_LZ4_LEFT_HEAD = 22,   // two-stage LZ4 path: entries handed to the general decoder, its dequeue head
        C_LZ4_TWO_OK = 23,                       // entries finished by the two-stage path
        C_LZ4_BUMP = 24,                         // (two words, 8-byte aligned) record-arena allocator of k_lz4_parse
+       C_ENC_CLASS = 28,                        // (three words) encode batches: does the batch hold entries for k_encode<12> / <13> / <14> at all
        C_ORDER_SPAN = 26,                       // (two words) largest size class and largest 15 - class among the Zstandard / LZ4 entries
        C_ORDER = 32,                            // k_order_*: [2 lists][16 classes] entry counts, then the same again as fill cursors
        N_COUNTERS = 32 + 64 };
