@@ -435,7 +435,7 @@ def main():
         lz4_names = "k_lz4_parse+k_lz4_exec+k_lz4_left" if dstats.get("lz4_two_stage_taken") else "k_lz4_wave"
         if rank == 0:
             ceiling = copy_ceiling()
-            tr = pmc_traffic(args.workload, n, KNAMES[kern], sha)
+            tr = pmc_traffic(args.workload, n, KNAMES[kern] + (KNAMES["lz4"] if w["method"] < 0 else []), sha)      # (a mixed batch: all its decode kernels)
             cpu = None
             if not args.no_cpu and world == 1:                      # the CPU leg is reported at N=1 only
                 cpu = cpu_baseline_decode(batch, args.cpu_seconds, ncores)

@@ -34,9 +34,13 @@ b)
   trace c3_zstd --workload c3_zstd_256k --steps 3 --warmup 1
   pmc2 c3 c3_zstd_256k 100000 --workload c3_zstd_256k
   timeout -k 10 900 python bench.py --workload c3_zstd_256k --steps 3 --warmup 1 > $out/${tag}_c3_zstd_bench.json 2> $out/c3.err; echo "bench c3 rc=$?"; line c3_zstd
+  pmc2 c4 c4_mixed 125000 --workload c4_mixed
   timeout -k 10 900 python bench.py --workload c4_mixed --steps 3 --warmup 1 > $out/${tag}_c4_mixed_bench.json 2> $out/c4.err; echo "bench c4 rc=$?"; line c4_mixed
   timeout -k 10 600 python bench.py --gpus 4 --workload c4_mixed --entries 40000 --steps 3 --warmup 1 --no-cpu > $out/${tag}_c4_4rank_40000_one_card_rehearsal.json 2> $out/strong.err; echo "4-rank rc=$?"; cut -c1-300 $out/${tag}_c4_4rank_40000_one_card_rehearsal.json
   timeout -k 10 600 python bench.py --gpus 2 --workload c5_zstd1_1m --entries 600 --steps 2 --warmup 1 --no-cpu > $out/${tag}_c5_2rank_one_card_rehearsal.json 2> $out/c5x2.err; echo "c5 2-rank rc=$?" ;;
+b4)   # (only the C4 part of b)
+  pmc2 c4 c4_mixed 125000 --workload c4_mixed
+  timeout -k 10 900 python bench.py --workload c4_mixed --steps 3 --warmup 1 > $out/${tag}_c4_mixed_bench.json 2> $out/c4.err; echo "bench c4 rc=$?"; line c4_mixed ;;
 c)
   { python3 tools/host_rate.py 20000 2 2>&1 | tail -2; python3 tools/host_rate.py 60000 2 2>&1 | tail -1; python3 tools/host_rate.py 8000 1 2>&1 | tail -1; } | tee $out/${tag}_host_rate.txt
   { python3 tools/host_write_rate.py 4000 1048576 1 1 2>&1 | grep -v amdgpu.ids | tail -3; python3 tools/host_write_rate.py 40000 65536 2 0 2>&1 | grep -v amdgpu.ids | tail -3; } | tee $out/${tag}_host_write_rate.txt
