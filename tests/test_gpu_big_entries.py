@@ -178,3 +178,29 @@ def test_big_entry_through_zpack_h_and_the_compiled_reference(tmp_path):
             rc, out = R.read_file(r, 0, len(plain))
             assert rc == 0 and out == plain.tobytes(), "the reference rejects the frame sequence"
             R.close_reader(r)
+
+
+def test_split_options_through_the_environment_of_zpack_h(monkeypatch):
+    """zpack.h has no place for codec options: a context reads ZPACK_AMD_ENC_SPLIT_MIN / _DEC_SPLIT_MIN when it is created.  0 = one
+    frame per entry whatever its size (byte-identical archives across library versions), the default cuts at 2 MiB."""
+    from tests._libs import ZPackAPI
+    from tests import zpk
+    from tests.test_gpu_zpack_api import _count_frames
+    Z = ZPackAPI(zpack_amd.ZPACK_SO)
+    plain = dg.fill(dg.TEXT, 8, 2, 3 * M + 5).tobytes()
+    frames = {}
+    for setting in ("0", None, str(1 << 20)):
+        if setting is None:
+            monkeypatch.delenv("ZPACK_AMD_ENC_SPLIT_MIN", raising=False)
+        else:
+            monkeypatch.setenv("ZPACK_AMD_ENC_SPLIT_MIN", setting)
+        arc = Z.write_archive([("f", plain), ("g", plain[:(3 * M) // 2])], METHOD_LZ4, 0)       # (a writer makes its context on first use)
+        ents = zpk.parse(arc)
+        frames[setting] = [_count_frames(arc[e["offset"]:e["offset"] + e["comp_size"]], METHOD_LZ4) for e in ents]
+        rc, r, keep = Z.open_memory(arc)
+        assert rc == 0
+        for i, want in enumerate((plain, plain[:(3 * M) // 2])):
+            rc, out = Z.read_file(r, i, len(want))
+            assert rc == 0 and out == want
+        Z.close_reader(r)
+    assert frames["0"] == [1, 1] and frames[None] == [7, 1] and frames[str(1 << 20)] == [7, 3], frames

@@ -46,7 +46,18 @@ zi_ctx* zi_ctx_create(void)
     zi_ctx* x = (zi_ctx*)calloc(1, sizeof(*x));
     if (!x) return NULL;
     for (int i = 0; i < n; i++) {
-        if (zpk_codec_create(&x->dev[x->n], devs[i]) == ZPK_OK) x->n++;
+        if (zpk_codec_create(&x->dev[x->n], devs[i]) == ZPK_OK) {
+            /* zpack.h has no place for codec options: a deployment sets them through the environment (bytes; 0 = never).  Entries of at
+             * least ZPACK_AMD_ENC_SPLIT_MIN bytes are written as sequences of 512 KiB frames (other bytes than one frame, same
+             * plaintext; default 2 MiB), entries of at least ZPACK_AMD_DEC_SPLIT_MIN that are such sequences are read one wave per frame. */
+            static const struct { const char* env; int opt; } knobs[] = {
+                { "ZPACK_AMD_ENC_SPLIT_MIN", ZPK_OPT_ENC_SPLIT_MIN }, { "ZPACK_AMD_DEC_SPLIT_MIN", ZPK_OPT_DEC_SPLIT_MIN }, { "ZPACK_AMD_ORDER_MIN", ZPK_OPT_ORDER_MIN } };
+            for (size_t k = 0; k < sizeof(knobs) / sizeof(knobs[0]); k++) {
+                const char* v = getenv(knobs[k].env);
+                if (v && *v) { char* end = NULL; long long q = strtoll(v, &end, 10); if (end && *end == 0 && q >= 0 && q <= 0x7FFFFFFF) (void)zpk_codec_set_option(x->dev[x->n], knobs[k].opt, (int)q); }
+            }
+            x->n++;
+        }
     }
     if (x->n == 0) { free(x); return NULL; }
     return x;
