@@ -50,6 +50,8 @@ c)
   { timeout -k 10 300 python3 tools/enc_bench.py 4000 1048576 1 2>&1 | grep -E "^(text|records|random|runs) "; timeout -k 10 300 python3 tools/enc_bench.py 2000 1048576 3 2>&1 | grep -E "^(text|records|random|runs) "; } | tee $out/${tag}_enc_classes_levels.txt ;;
 d)
   timeout -k 10 1100 python3 tools/fuzz_gpu.py 400 11 all > $out/${tag}_fuzz_all.log 2>&1; echo "fuzz rc=$?"; tail -8 $out/${tag}_fuzz_all.log ;;
+d2)   # the same frames with every batch's work lists ordered (the default orders batches of >= 8192 entries only)
+  ZPK_FUZZ_ORDER_MIN=1 timeout -k 10 1100 python3 tools/fuzz_gpu.py 400 13 all > $out/${tag}_fuzz_ordered.log 2>&1; echo "fuzz rc=$?"; tail -8 $out/${tag}_fuzz_ordered.log ;;
 e)
   tools/r4_ab.sh $tag skip-tests 2>&1 | tee $out/${tag}_lz4_two_stage_ab.txt ;;
 g)

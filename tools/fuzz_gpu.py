@@ -23,6 +23,9 @@ if os.environ.get("ZPK_FUZZ_LZ4_TWO") in ("slot", "window"):
     codec.set_option(zpack_amd.OPT_LZ4_TWO_STAGE_MAX_COMP, 4 << 20)
     codec.set_option(zpack_amd.OPT_LZ4_EXEC_WINDOW, 1 if os.environ["ZPK_FUZZ_LZ4_TWO"] == "window" else 0)
     print("two-stage LZ4 path:", os.environ["ZPK_FUZZ_LZ4_TWO"])
+if os.environ.get("ZPK_FUZZ_ORDER_MIN"):                       # 1: every batch runs its work lists largest entries first (default: batches of >= 8192 entries)
+    codec.set_option(zpack_amd.OPT_ORDER_MIN, int(os.environ["ZPK_FUZZ_ORDER_MIN"]))
+    print("work lists ordered from", os.environ["ZPK_FUZZ_ORDER_MIN"], "entries")
 only_lz4 = len(sys.argv) > 3 and sys.argv[3] == "lz4"
 o = oracle()
 dev = torch.device("cuda:0")
