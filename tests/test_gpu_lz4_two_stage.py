@@ -23,6 +23,8 @@ def codec2(request):
     c = zpack_amd.Codec(0)
     c.set_option(zpack_amd.OPT_LZ4_TWO_STAGE_MIN, 0)
     c.set_option(zpack_amd.OPT_LZ4_EXEC_WINDOW, request.param)
+    if request.param:
+        c.set_option(zpack_amd.OPT_ORDER_MIN, 1)          # ... and, for one of the two, every batch's work lists largest entries first
     return c
 
 
