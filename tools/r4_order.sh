@@ -9,7 +9,7 @@ d=json.loads(open("$out/order_tmp.json").read().strip().splitlines()[-1]); r=d["
 print(sys.argv[1], round(d["value"],1), d["unit"], round(d["ms_per_step"],2), "ms/step; stages", r.get("stage_ms"), "parity", d["parity"])
 PY
 }
-run "c4 archive order " --workload c4_mixed --steps 3 --warmup 1 && \
+run "c4 default (1st)  " --workload c4_mixed --steps 3 --warmup 1 && \
 ZPK_BENCH_ORDER_MIN=0 run "c4 archive order (ORDER_MIN=0)" --workload c4_mixed --steps 3 --warmup 1 && \
 run "c4 default        " --workload c4_mixed --steps 3 --warmup 1 && \
 ZPK_BENCH_ORDER_MIN=0 run "c2 ORDER_MIN=0    " --steps 20 --warmup 3 && \
