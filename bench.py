@@ -216,6 +216,41 @@ def spawn_ranks(n, argv):
     return p.returncode if p.returncode != 0 or line is not None else 1
 
 
+def shard_plan(workload, world, rank, entries=0, scaling=None):
+    """What rank `rank` of `world` owns of a workload — derived from sizes alone (a function of the seed and the index), so that every rank
+    computes the same plan without building anything, and so that tests/test_shard_gloo.py can check the 8-rank plan of BASELINE.json
+    configs[3] / [4] on the CPU.  -> dict(n_total, lo, hi, one_archive, strong, scaling, seed)
+      c4_mixed: ONE archive of 125 000 x world entries (1 000 000 at 8 ranks), contiguous CDR ranges balanced by UNCOMPRESSED bytes
+                (compressed sizes are not known before compressing; the ratio of a slice of tens of thousands of seeded entries is the
+                corpus mean: the comp+uncomp balance of the real archive is checked in tests/test_shard_gloo.py on a sample);
+      c2 / c3 / stored: one batch of n entries per rank (weak), seed + 1000 * rank;
+      c5_zstd1_1m: one archive of n x world source files, rank r owns files [r n, (r + 1) n)."""
+    import numpy as np
+    from benchdata import datagen as dg
+    from zpack_amd.shard import shard_ranges
+    w = dict(WORKLOADS[workload])
+    if entries:
+        w["n"] = entries
+    one_archive = (workload == "c4_mixed" or scaling == "strong") and w["kind"] == "decode"
+    fixed_total = scaling == "strong" or (workload == "c4_mixed" and entries > 0)
+    if scaling is None:
+        scaling = "strong" if (workload == "c4_mixed" and entries > 0) else "weak"
+    if one_archive:
+        n_total = w["n"] if fixed_total else w["n"] * world
+        us_all = dg.sizes(n_total, w["lo"], w["hi"], w["seed"])
+        lo, hi = shard_ranges(np.zeros(n_total, dtype=np.uint64), us_all, world)[rank]
+        seed = w["seed"]
+    elif w["kind"] == "encode":
+        n_total = w["n"] * world
+        lo, hi = rank * w["n"], (rank + 1) * w["n"]
+        seed = w["seed"]
+    else:
+        n_total = w["n"] * world
+        lo, hi = 0, w["n"]
+        seed = w["seed"] + 1000 * rank
+    return dict(n_total=int(n_total), lo=int(lo), hi=int(hi), one_archive=one_archive, strong=one_archive and fixed_total, scaling=scaling, seed=seed)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +268,7 @@ def main():
     args = ap.parse_args()
     # c4_mixed (BASELINE.json configs[3]) is ONE archive sharded statically over the ranks: 125 000 entries per GPU, i.e. the config's
     # 1 000 000 entries at --gpus 8 (per-GPU work fixed: "weak"); --entries N or --scaling strong fix the archive's TOTAL instead
+    scaling_arg = args.scaling
     one_archive = args.workload == "c4_mixed" or args.scaling == "strong"
     fixed_total = args.scaling == "strong" or (args.workload == "c4_mixed" and args.entries > 0)
     if args.scaling is None:
@@ -353,17 +389,13 @@ def main():
         # [lo, hi) alone ("GPU g gets descriptors + its slice of the packed stream in its own HBM") ----
         t0 = time.time()
         flags = zpack_amd.DF_SKIP_HASH if args.skip_hash else 0
+        plan = shard_plan(args.workload, world, rank, args.entries, scaling_arg)
+        n_total, lo, hi = plan["n_total"], plan["lo"], plan["hi"]
+        assert plan["one_archive"] == one_archive
         if one_archive:
-            n_total = w["n"] if fixed_total else w["n"] * world
-            us_all = dg.sizes(n_total, w["lo"], w["hi"], w["seed"])
-            # (compressed sizes are not known before compressing: the balance is by uncompressed bytes — the ratio of a slice of a
-            # few thousand seeded entries is the corpus mean)
-            lo, hi = shard_ranges(np.zeros(n_total, dtype=np.uint64), us_all, world)[rank]
-            batch = dg.Batch(hi - lo, w["lo"], w["hi"], method=w["method"], level=w["level"], seed=w["seed"], mix=args.mix, threads=gen_threads, first=lo)
+            batch = dg.Batch(hi - lo, w["lo"], w["hi"], method=w["method"], level=w["level"], seed=plan["seed"], mix=args.mix, threads=gen_threads, first=lo)
         else:
-            n_total = w["n"] * world
-            lo, hi = 0, w["n"]
-            batch = dg.Batch(w["n"], w["lo"], w["hi"], method=w["method"], level=w["level"], seed=w["seed"] + 1000 * rank, mix=args.mix, threads=gen_threads)
+            batch = dg.Batch(w["n"], w["lo"], w["hi"], method=w["method"], level=w["level"], seed=plan["seed"], mix=args.mix, threads=gen_threads)
         t_gen = time.time() - t0
         desc, dst_bytes = zpack_amd.decode_descs_from_batch(batch, flags=flags)
         n = batch.n

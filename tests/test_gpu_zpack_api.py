@@ -552,6 +552,48 @@ def test_stream_read_small_windows_do_not_launch_per_call(Z):
     Z.lib.zpack_close_reader(C.byref(r))
 
 
+@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 3)])
+def test_stream_read_with_window_sizes_that_change_between_calls(Z, method, level):
+    """zpack_stream lets avail_in differ from call to call (lib/zpack_read.c:515-640 reads whatever window it is handed).  Two entries
+    in a row on ONE stream, each fed a 16-byte window first (gathered on the host, no launch) and 1 MiB windows afterwards (the
+    entry's first DEVICE step then starts with bytes already counted): the resume record of the first entry must not leak into the
+    second (round-4 advisor finding: freshness was decided after the gather branch had moved the bytes)."""
+    sizes = (3 << 20, (2 << 20) + 12345)
+    plains = [dg.fill(dg.TEXT if k == 0 else dg.RECORDS, 77 + k, k, n) for k, n in enumerate(sizes)]
+    frames = [bytes(dg.compress(method, level, p_)) for p_ in plains]
+    ents, off = [], 10
+    for k, f in enumerate(frames):
+        ents.append(("e%d" % k, off, len(f), sizes[k], dg.xxh3(plains[k]), method)); off += len(f)
+    arc = zpk.assemble(frames, ents)
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    st = Stream()
+    assert Z.lib.zpack_init_stream(C.byref(st)) == 0
+    big = 1 << 20
+    in_buf = (C.c_uint8 * big)(); out_buf = (C.c_uint8 * big)()
+    for k in range(2):
+        e = r.file_entries[k]
+        Z.lib.zpack_reset_stream(C.byref(st))
+        sink = np.zeros(sizes[k], dtype=np.uint8)
+        pos = calls = 0
+        while not (st.total_in == e.comp_size and st.total_out == e.uncomp_size and st.read_back == 0):
+            win = 16 if calls == 0 else big
+            if st.read_back:
+                tail = C.string_at(C.addressof(st.next_in.contents) - st.read_back, st.read_back)
+                C.memmove(in_buf, tail, st.read_back)
+            st.next_in = C.cast(in_buf, u8p); st.avail_in = win
+            st.next_out = C.cast(out_buf, u8p); st.avail_out = big
+            rc = Z.lib.zpack_read_file_stream(C.byref(r), C.byref(e), C.byref(st), None)
+            assert rc == 0, (k, calls, rc)
+            got = big - st.avail_out
+            sink[pos:pos + got] = np.frombuffer(out_buf, dtype=np.uint8, count=got); pos += got
+            calls += 1
+            assert calls < 10000
+        assert pos == sizes[k] and np.array_equal(sink, plains[k]), k
+    Z.lib.zpack_close_stream(C.byref(st))
+    Z.lib.zpack_close_reader(C.byref(r))
+
+
 @pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 1)])
 def test_host_write_batch_of_many_ragged_entries(method, level):
     """zpk_codec_encode_batch_host (what zpack_write_files calls once per batch) on 15 000 entries of ragged sizes (~750 MB: the sources

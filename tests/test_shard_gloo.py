@@ -175,3 +175,82 @@ def test_two_rank_write_path_archive_offsets_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert chain and ok
+
+
+# ---- world_size 8 on the CPU: the plans of BASELINE.json configs[3] and [4] as bench.py --gpus 8 would run them (sizes only, no archive) --------
+
+def _plan8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from benchdata import datagen as dg
+    # configs[3]: ONE archive of 125 000 x 8 = 1 000 000 entries, 4 KiB .. 1 MiB, sharded by bytes; every rank derives its range alone
+    plan = bench.shard_plan("c4_mixed", world, rank)
+    w = bench.WORKLOADS["c4_mixed"]
+    us = dg.sizes(plan["n_total"], w["lo"], w["hi"], w["seed"])
+    lo, hi = plan["lo"], plan["hi"]
+    # what a rank would gather: one record per entry of its slice (here: the entry's global index and size — the stand-in for the 24-byte
+    # results; the real codec runs in the 2-rank tests above), in CDR order on rank 0
+    local = np.zeros(hi - lo, dtype=np.dtype([("index", "<u8"), ("size", "<u8")]))
+    local["index"] = np.arange(lo, hi, dtype=np.uint64)
+    local["size"] = us[lo:hi]
+    allr = gather_results(local, lo, hi, plan["n_total"], rank, world, dist)
+    mine = torch.tensor([float(lo), float(hi), float(us[lo:hi].astype(np.float64).sum())], dtype=torch.float64)
+    every = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(every, mine)
+    # configs[4]: one archive of 12 500 x 8 source files; rank r compresses files [r n, (r + 1) n) and the archive offsets come from a host
+    # scan of the per-rank segment totals (lib/zpack_write.c:338 across ranks).  Stand-in totals: a seeded "compressed size" per file.
+    p5 = bench.shard_plan("c5_zstd1_1m", world, rank)
+    rng = np.random.default_rng(1234)
+    comp = rng.integers(300_000, 500_000, p5["n_total"], dtype=np.uint64)          # the same table on every rank
+    seg_total = int(comp[p5["lo"]:p5["hi"]].sum())
+    totals = gather_segment_totals(seg_total, rank, world, dist)
+    bases, end = archive_bases(totals)
+    local_off = np.uint64(bases[rank]) + np.concatenate([[np.uint64(0)], np.cumsum(comp[p5["lo"]:p5["hi"]])[:-1]]).astype(np.uint64)
+    off_all = gather_results(local_off, p5["lo"], p5["hi"], p5["n_total"], rank, world, dist)
+    if rank == 0:
+        ranges = [(int(e[0]), int(e[1])) for e in every]
+        loads = np.array([float(e[2]) for e in every])
+        cover = ranges[0][0] == 0 and ranges[-1][1] == plan["n_total"] and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        order_ok = bool(np.array_equal(allr["index"], np.arange(plan["n_total"], dtype=np.uint64)) and np.array_equal(allr["size"], us))
+        want_off = np.uint64(10) + np.concatenate([[np.uint64(0)], np.cumsum(comp)[:-1]]).astype(np.uint64)
+        q.put(dict(n_total=plan["n_total"], scaling=plan["scaling"], cover=cover, imbalance=float(loads.max() / loads.mean()), order_ok=order_ok,
+                   c5_total=p5["n_total"], c5_chain_ok=bool(np.array_equal(off_all, want_off)) and end == 10 + int(comp.sum()),
+                   c5_ranges_ok=all(bench.shard_plan("c5_zstd1_1m", world, r)["lo"] == r * 12500 for r in range(world))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_plans_of_configs_3_and_4_gloo():
+    """BASELINE.json configs[3] = 1 M mixed entries over 8 GPUs, configs[4] = 100 k x 1 MiB sources over 8 GPUs.  No 8-GPU node has been
+    available to any round; this runs the PLAN bench.py --gpus 8 executes (bench.shard_plan, zpack_amd/shard.py) on 8 gloo ranks with
+    the real size table of the config: the ranges tile [0, 1 000 000), bytes per rank within 5 % of the mean, results gathered in CDR
+    order on rank 0, the line would say entries_total = 1 000 000; the write path's offset chain across 8 ranks equals the serial
+    `write_offset += comp_size` (lib/zpack_write.c:338)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_plan8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    r = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert r["n_total"] == 1_000_000 and r["scaling"] == "weak" and r["cover"] and r["order_ok"], r
+    assert r["imbalance"] < 1.05, r
+    assert r["c5_total"] == 100_000 and r["c5_chain_ok"] and r["c5_ranges_ok"], r
+
+
+def test_c4_balance_by_uncompressed_bytes_is_good_enough():
+    """bench.py balances configs[3] by UNCOMPRESSED bytes (compressed sizes are not known before compressing).  On a real sample of the
+    corpus (4 000 entries, both methods, all classes) the comp+uncomp load of 8 such ranges stays within 8 % of the mean."""
+    from benchdata import datagen as dg
+    b = dg.Batch(4000, 4096, 1 << 20, method=dg.COIN, level=3, seed=3, threads=4)
+    r = shard_ranges(np.zeros(b.n, dtype=np.uint64), b.uncomp_sizes, 8)
+    w = (b.comp_sizes + b.uncomp_sizes).astype(np.float64)
+    loads = np.array([w[lo:hi].sum() for lo, hi in r])
+    assert loads.max() / loads.mean() < 1.08, loads

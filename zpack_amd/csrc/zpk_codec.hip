@@ -710,7 +710,7 @@ struct zpk_codec {
     int fell_back_fused = 0;     // the last decode batch could not get its sequence arena and ran the fused decoder only
     // the host-path pipeline decodes one call in several launches: their counters are brought back piece by piece and summed, so that
     // decode_stats / decode_stats2 describe the whole call (a retry or watchdog event in an early piece is not lost)
-    u32 piece_counters[64][N_COUNTERS] = {};
+    u32 (*piece_counters)[N_COUNTERS] = nullptr;     // [64], pinned (pin_ready): a D2H copy into pageable memory would block the launcher thread per piece
     u32 host_totals[N_COUNTERS] = {};
     int totals_valid = 0;
     char err[256] = {0};
@@ -794,6 +794,7 @@ void zpk_codec_destroy(zpk_codec* c)
     (void)hipFree(c->d_counters); (void)hipFree(c->d_lists); (void)hipFree(c->d_lit);
     (void)hipFree(c->d_src); (void)hipFree(c->d_dst); (void)hipFree(c->d_desc); (void)hipFree(c->d_res);
     for (int k = 0; k < 2; k++) { if (c->h_pin[k]) (void)hipHostFree(c->h_pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
+    if (c->piece_counters) (void)hipHostFree(c->piece_counters);
     if (c->h_seen) (void)hipHostFree((void*)c->h_seen);
     if (c->s_side) (void)hipStreamDestroy(c->s_side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1086,9 +1087,10 @@ static int rehash_short_entries(zpk_codec* c, const zpk_decode_desc* hd, const z
 #endif
 static int pin_ready(zpk_codec* c)
 {
+    if (!c->piece_counters && hipHostMalloc((void**)&c->piece_counters, 64 * N_COUNTERS * sizeof(u32), hipHostMallocDefault) != hipSuccess) { c->piece_counters = nullptr; return ZPK_E_NOMEM; }
     for (int k = 0; k < 2; k++) {
         if (!c->h_pin[k] && hipHostMalloc((void**)&c->h_pin[k], ZPK_PIN_CHUNK, ZPK_PIN_FLAGS) != hipSuccess) { c->h_pin[k] = nullptr; snprintf(c->err, sizeof(c->err), "pinned staging: out of memory"); return ZPK_E_NOMEM; }
-        if (!c->pin_ev[k] && hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { c->pin_ev[k] = nullptr; return ZPK_E_LAUNCH; }
+        if (!c->pin_ev[k] && hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { c->pin_ev[k] = nullptr; return ZPK_E_LAUNCH; }
     }
     return ZPK_OK;
 }
@@ -1302,7 +1304,7 @@ static int decode_host_pipelined(zpk_codec* c, const u8* image, u64 image_size, 
     if (!c->s_up && hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking) != hipSuccess) { c->s_up = nullptr; return ZPK_OK; }
     if (!c->s_dn && hipStreamCreateWithFlags(&c->s_dn, hipStreamNonBlocking) != hipSuccess) { c->s_dn = nullptr; return ZPK_OK; }
     for (int k = 0; k < 2 * np; k++)
-        if (!c->pipe_ev[k] && hipEventCreateWithFlags(&c->pipe_ev[k], hipEventDisableTiming) != hipSuccess) { c->pipe_ev[k] = nullptr; return ZPK_OK; }
+        if (!c->pipe_ev[k] && hipEventCreateWithFlags(&c->pipe_ev[k], hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { c->pipe_ev[k] = nullptr; return ZPK_OK; }
     taken = true;
     hipError_t e = hipMemcpyAsync(c->d_desc, hd, n * sizeof(zpk_decode_desc), hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }

@@ -32,9 +32,10 @@ def _coll_device(dist):
 
 
 def gather_results(local, lo, hi, n, rank, world, dist=None):
-    """Concatenate per-rank result arrays (numpy structured or plain) in CDR order on rank 0; no collective on the data path.
-    Tensor collectives only (all_gather of the ranges and of the byte images, padded to the longest): the same code under gloo on
-    the CPU and under RCCL on the GPUs — no pickling through object collectives."""
+    """Concatenate per-rank result arrays (numpy structured or plain: 24-byte results, hashes, sizes — bookkeeping, never entry
+    payloads) in CDR order on rank 0; no collective on the data path.  Tensor collectives only — an all_gather of the (lo, hi) ranges
+    (16 bytes per rank) and ONE gather to rank 0 of the byte images padded to the longest slice, so only rank 0 holds world x longest
+    bytes: the same code under gloo on the CPU and under RCCL on the GPUs, no pickling through object collectives."""
     if world == 1 or dist is None:
         return local
     import torch
@@ -49,8 +50,8 @@ def gather_results(local, lo, hi, n, rank, world, dist=None):
     raw = np.frombuffer(np.ascontiguousarray(local).tobytes(), dtype=np.uint8)
     if raw.size:
         buf[:raw.size] = torch.from_numpy(raw.copy()).to(dev)
-    parts = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf)
+    parts = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gather_list=parts, dst=0)
     if rank != 0:
         return None
     out = np.zeros(n, dtype=local.dtype)
