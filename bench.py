@@ -47,7 +47,7 @@ WORKLOADS = {
     # encode: BASELINE.json configs[4] per GPU (100k x 1 MiB over 8 GPUs = 12 500 per GPU), Zstandard level 1 + XXH3
     "c5_zstd1_1m": dict(kind="encode", n=12500, lo=1 << 20, hi=1 << 20, method=1, level=1, seed=4, kernel="encode"),
 }
-KNAMES = {"lz4": ["k_lz4_parse", "k_lz4_exec", "k_lz4_left", "k_lz4_wave"],      # two-stage path (large batches) / one-kernel path
+KNAMES = {"lz4": ["k_lz4_wave", "k_lz4_left"],      # the one-wave decoder; its build for entries of long runs
           "zstd": ["k_zstd_fse", "k_zstd_exec", "k_zstd"], "stored": ["k_stored"], "encode": ["k_encode"]}
 
 
@@ -315,16 +315,10 @@ def main():
     ncores = len(os.sched_getaffinity(0))
     gen_threads = max(1, ncores // max(1, world))
     codec = zpack_amd.Codec(local_rank)
-    if os.environ.get("ZPK_BENCH_LZ4_TWO") in ("never", "always"):            # A/B of the two LZ4 decode paths (the line's kernel names say which ran)
-        codec.set_option(zpack_amd.OPT_LZ4_TWO_STAGE_MIN, 0x7FFFFFFF if os.environ["ZPK_BENCH_LZ4_TWO"] == "never" else 0)
     if os.environ.get("ZPK_BENCH_ORDER_MIN"):                               # A/B: work lists largest entries first (0 = never)
         codec.set_option(zpack_amd.OPT_ORDER_MIN, int(os.environ["ZPK_BENCH_ORDER_MIN"]))
     if os.environ.get("ZPK_BENCH_ORDER_FAST"):
         codec.set_option(zpack_amd.OPT_ORDER_FAST_LAST, int(os.environ["ZPK_BENCH_ORDER_FAST"]))
-    if os.environ.get("ZPK_BENCH_LZ4_EXEC_WINDOW"):
-        codec.set_option(5, int(os.environ["ZPK_BENCH_LZ4_EXEC_WINDOW"]))
-    if os.environ.get("ZPK_BENCH_LZ4_EXEC_PAD"):                            # measurement aid: fewer LZ4 entries in flight per CU
-        codec.set_option(4, int(os.environ["ZPK_BENCH_LZ4_EXEC_PAD"]))
     stream = torch.cuda.current_stream().cuda_stream
     sha = csrc_sha1()
     red_dev = torch.device("cpu") if rehearsal else dev
@@ -414,9 +408,6 @@ def main():
             kids = [zpack_amd.K_LZ4] + kids
         stage_ms = [codec.kernel_ms(k) for k in kids] if n else [0.0]      # the LAST timed launch's kernels
         dstats = codec.decode_stats()
-        lz4_parse_ms = None
-        if dstats.get("lz4_two_stage_taken"):                           # k_lz4_parse inside the K_LZ4 bracket (two-stage path only)
-            lz4_parse_ms = codec.kernel_ms(zpack_amd.K_LZ4_PARSE)
         codec.set_profiling(False)
         my_uncomp = float(batch.uncomp_sizes.sum()) if n else 0.0
         my_comp = float(batch.comp_sizes.sum()) if n else 0.0
@@ -434,6 +425,7 @@ def main():
             res_all = gather_results(res_local, lo, hi, n_total, rank, world, dist)
             ref_all = gather_results(np.ascontiguousarray(batch.hashes), lo, hi, n_total, rank, world, dist)
             if rank == 0:
+                us_all = dg.sizes(n_total, w["lo"], w["hi"], plan["seed"])
                 gathered_ok = bool((res_all["status"] == 0).all() and np.array_equal(res_all["hash"], ref_all) and
                                    np.array_equal(res_all["produced"], us_all))
         bytes_ok = True
@@ -464,7 +456,7 @@ def main():
         k_ms = float(ev_ms / args.steps) if overlapped else float(sum(stage_ms))
         alg_bytes = my_comp + my_uncomp                                    # each byte moved once, this rank's launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        lz4_names = "k_lz4_parse+k_lz4_exec+k_lz4_left" if dstats.get("lz4_two_stage_taken") else "k_lz4_wave"
+        lz4_names = "k_lz4_wave+k_lz4_left" if dstats.get("lz4_long_runs") else "k_lz4_wave"
         if rank == 0:
             ceiling = copy_ceiling()
             tr = pmc_traffic(args.workload, n, KNAMES[kern] + (KNAMES["lz4"] if w["method"] < 0 else []), sha)      # (a mixed batch: all its decode kernels)
@@ -498,7 +490,7 @@ def main():
                              "traffic": tr["traffic"], "traffic_fetch_raw": tr["fetch_raw"], "traffic_write": tr["write"],
                              "traffic_source": tr["note"], "csrc_sha1": sha,
                              "kernel": "+".join(([lz4_names] if w["method"] < 0 else []) + ([lz4_names] if kern == "lz4" else KNAMES[kern])),
-                             "kernel_ms": k_ms, "stage_ms": stage_ms, "lz4_parse_ms": lz4_parse_ms,
+                             "kernel_ms": k_ms, "stage_ms": stage_ms, "lz4_entries_of_long_runs": dstats.get("lz4_long_runs"),
                              "stage_names": ([lz4_names] if w["method"] < 0 else []) + {"lz4": [lz4_names],
                                              "zstd": ["k_zstd_fse", "k_zstd_exec+k_zstd"], "stored": ["k_stored"]}[kern],
                              "kernel_ms_source": ("HIP events around the whole batch on the launch stream, mean over the timed steps: the LZ4 stage runs beside the "

@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define ZPK_CODEC_ABI_VERSION 2      /* 2: set_option has options again, decode_stats2 out[2..4], ZPK_K_LZ4_PARSE */
+#define ZPK_CODEC_ABI_VERSION 3      /* 3: the two-stage LZ4 path of version 2 is gone (options 2..5 are ZPK_E_INVALID again, decode_stats2 out[2] = out[4] = 0,
+                                        out[3] = LZ4 entries that are mostly runs, decoded by k_lz4_left); 2: set_option has options again */
 
 /* return codes of the zpk_* entry points themselves (not per-entry statuses) */
 enum {
@@ -114,13 +115,6 @@ void        zpk_codec_reset(zpk_codec* c);                  /* after an abandone
 const char* zpk_codec_last_error(const zpk_codec* c);
 int         zpk_codec_device(const zpk_codec* c);
 /* options (ZPK_E_INVALID for anything else):
- *   ZPK_OPT_LZ4_TWO_STAGE_MIN       decode batches of at least `value` entries run their LZ4 entries in two stages — token chains one
- *                                   LANE per entry, then execution one wave per entry from the records (lz4_two.h); smaller batches
- *                                   take the one-kernel decoder.  0 = every batch, INT_MAX = never = the DEFAULT: on the headline
- *                                   workload the path measured slower than the one-kernel decoder (profiles/r04).
- *   ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP  ... for entries of at most `value` compressed bytes (one lane walks one entry; longer entries
- *                                   stay with the one-wave decoder).  Default 96 KiB.
- * The results are identical either way (every irregular entry is decoded by the general decoder, which alone gives verdicts).
  *   ZPK_OPT_ENC_SPLIT_MIN           zpk_codec_encode_batch_host: an entry of at least `value` bytes is compressed as a SEQUENCE OF
  *                                   FRAMES, one per 512 KiB of plaintext, all of them side by side (one wave encodes one frame: a
  *                                   256 MiB entry is 512 waves instead of one), its XXH3 by the whole chip (per-block partial sums,
@@ -135,9 +129,8 @@ int         zpk_codec_device(const zpk_codec* c);
  *                                   FIRST (size classes by powers of two; a device counting sort behind the classification): one
  *                                   wave works on one entry, so a large entry that starts last runs on alone; encode batches order
  *                                   their ticket queue the same way.  Default 8192 (decode), 4608 (encode); 0 = never. */
-enum { ZPK_OPT_LZ4_TWO_STAGE_MIN = 2, ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP = 3, ZPK_OPT_ENC_SPLIT_MIN = 6, ZPK_OPT_DEC_SPLIT_MIN = 7, ZPK_OPT_ORDER_MIN = 8, ZPK_OPT_ORDER_FAST_LAST = 9 /* a batch of ONE size class runs the entries that did not compress (a copy to decode) last: 1 (default) / 0 */,
-       ZPK_OPT_LZ4_EXEC_WINDOW = 5 /* stage 2 of the two-stage path: 1 = output assembled in an LDS window, 0 = in the output slot */,
-       ZPK_OPT_DEV_LZ4_EXEC_PAD = 4 /* measurement aid: bytes of idle LDS per stage-2 workgroup, i.e. fewer entries in flight per CU */ };
+/* (2..5 were the opt-in two-stage LZ4 path of round 4 and its measurement aids: measured slower than the one-kernel decoder, removed in round 5) */
+enum { ZPK_OPT_ENC_SPLIT_MIN = 6, ZPK_OPT_DEC_SPLIT_MIN = 7, ZPK_OPT_ORDER_MIN = 8, ZPK_OPT_ORDER_FAST_LAST = 9 /* a batch of ONE size class runs the entries that did not compress (a copy to decode) last: 1 (default) / 0 */ };
 int         zpk_codec_set_option(zpk_codec* c, int option, int value);
 
 /* ---- batch decode + verify ----------------------------------------------------------------
@@ -189,13 +182,13 @@ int zpk_codec_hash_host(zpk_codec* c, const uint8_t* data, uint64_t size, uint64
 /* per-kernel timing of decode batches: when enabled, every decode batch brackets each of its kernels
  * with HIP events on the launch stream; zpk_codec_kernel_ms then returns the duration of kernel
  * `which` (ZPK_K_*) in the most recent batch (synchronises on that batch). */
-enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2 /* k_lz4_wave */, ZPK_K_ZSTD = 3 /* k_zstd_exec + k_zstd */, ZPK_K_ZSTD_FSE = 4,
-       ZPK_K_PACK = 5, ZPK_K_LZ4_PARSE = 6 /* k_lz4_parse, inside ZPK_K_LZ4's bracket */, ZPK_K_ENCODE = 7, ZPK_K_COUNT = 8 };
+enum { ZPK_K_CLASSIFY = 0, ZPK_K_STORED = 1, ZPK_K_LZ4 = 2 /* k_lz4_wave + k_lz4_left + k_lz4_retry */, ZPK_K_ZSTD = 3 /* k_zstd_exec + k_zstd */, ZPK_K_ZSTD_FSE = 4,
+       ZPK_K_PACK = 5, ZPK_K_RESERVED6 = 6 /* (was k_lz4_parse) */, ZPK_K_ENCODE = 7, ZPK_K_COUNT = 8 };
 int zpk_codec_set_profiling(zpk_codec* c, int enabled);
 /* out[0], out[1] = LZ4 / Zstandard entries of the most recent decode batch whose first decode ran out of its time budget (a
  * contended or preempted GPU) and that were decoded again, behind the batch, with a 64 x larger one — a slow wave is not a
- * verdict; expected 0 on an idle GPU.  out[2], out[3] = LZ4 entries finished by the two-stage path / handed by it to the general
- * decoder; out[4] = 1 when the batch took the two-stage path at all; out[5], out[6] = entries of the most recent
+ * verdict; expected 0 on an idle GPU.  out[3] = LZ4 entries that are mostly runs (compressed to less than 1/8: the classification puts
+ * them on the list of k_lz4_left, the build of the one-wave decoder with grouped cooperative copies); out[2] = out[4] = 0; out[5], out[6] = entries of the most recent
  * zpk_codec_decode_batch_host call that were decoded frame-parallel (ZPK_OPT_DEC_SPLIT_MIN) and the frames they had */
 int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16]);
 /* counters of the most recent decode batch (synchronises): out[0..2] = entries on the stored / zstd / lz4 work

@@ -24,7 +24,7 @@ def test_codec_library_exports_every_declared_symbol():
     assert len(names) >= 25
     assert [n for n in names if " T " + n not in syms] == []
     lib = C.CDLL(zpack_amd.CODEC_SO)
-    assert lib.zpk_codec_abi_version() == 2
+    assert lib.zpk_codec_abi_version() == 3
 
 
 def test_zpack_library_exports_the_reference_api():
@@ -127,9 +127,7 @@ def test_option_numbers_of_the_python_view_match_the_header():
     import re
     hdr = open(os.path.join(ROOT, "include", "zpack_codec.h")).read()
     nums = {m.group(1): int(m.group(2)) for m in re.finditer(r"(ZPK_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", hdr)}
-    view = {"ZPK_OPT_LZ4_TWO_STAGE_MIN": zpack_amd.OPT_LZ4_TWO_STAGE_MIN, "ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP": zpack_amd.OPT_LZ4_TWO_STAGE_MAX_COMP,
-            "ZPK_OPT_DEV_LZ4_EXEC_PAD": zpack_amd.OPT_DEV_LZ4_EXEC_PAD, "ZPK_OPT_LZ4_EXEC_WINDOW": zpack_amd.OPT_LZ4_EXEC_WINDOW,
-            "ZPK_OPT_ENC_SPLIT_MIN": zpack_amd.OPT_ENC_SPLIT_MIN, "ZPK_OPT_DEC_SPLIT_MIN": zpack_amd.OPT_DEC_SPLIT_MIN,
+    view = {"ZPK_OPT_ENC_SPLIT_MIN": zpack_amd.OPT_ENC_SPLIT_MIN, "ZPK_OPT_DEC_SPLIT_MIN": zpack_amd.OPT_DEC_SPLIT_MIN,
             "ZPK_OPT_ORDER_MIN": zpack_amd.OPT_ORDER_MIN, "ZPK_OPT_ORDER_FAST_LAST": zpack_amd.OPT_ORDER_FAST_LAST}
     assert nums == view, (nums, view)
     assert len(set(nums.values())) == len(nums)

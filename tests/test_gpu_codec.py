@@ -178,6 +178,44 @@ def test_device_batch_vs_oracle(codec, method, level, size, n):
         assert out[int(d["dst_offset"]):int(d["dst_offset"] + d["uncomp_size"])].tobytes() == want, i
 
 
+@pytest.mark.parametrize("mix,size,n", [(dg.RUNS, 65536, 300), (dg.RUNS, 1 << 20, 12), (dg.TEXT, 65536, 300), (dg.MIX, 40000, 400)])
+def test_lz4_entries_that_are_mostly_runs_go_to_their_own_kernel(codec, mix, size, n):
+    """round 5: an LZ4 entry that is mostly RUNS (compressed to less than an eighth: LZ4 writes a byte run as literal + match at distance
+    1 of ~165 bytes, a repeated block as one long match) goes on the list of k_lz4_left, the build of the one-wave decoder with grouped
+    cooperative copies (seq_exec.h COOP = 2); k_lz4_wave is the round-4 code.  With the XXH3 verify OFF every byte of every entry
+    must equal the oracle's either way, and the counters say which kernel had what: byte-run entries all the second kernel, text none."""
+    import torch
+    o = oracle()
+    b = dg.Batch(n, size, method=dg.LZ4, level=0, seed=23, mix=mix)
+    desc, total = zpack_amd.decode_descs_from_batch(b, flags=zpack_amd.DF_SKIP_HASH)
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(b.archive).to(dev)
+    dst = torch.full((total,), 0xA5, dtype=torch.uint8, device=dev)
+    ddesc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    dres = torch.zeros(n * zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+    codec.decode_batch_device(src, ddesc, n, dst, dres)
+    torch.cuda.synchronize()
+    res = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)
+    out = dst.cpu().numpy()
+    assert (res["status"] == 0).all(), res[res["status"] != 0][:5]
+    assert np.array_equal(res["produced"], b.uncomp_sizes) and np.array_equal(res["hash"], b.hashes)
+    arc = b.archive.tobytes()
+    for i in range(n):
+        d = desc[i]
+        rc, want, got, h = o.entry_decode(arc, int(d["src_offset"]), int(d["comp_size"]), int(d["uncomp_size"]),
+                                          int(d["expect_hash"]), int(d["method"]), int(d["dst_capacity"]))
+        assert rc == 0 and out[int(d["dst_offset"]):int(d["dst_offset"] + d["uncomp_size"])].tobytes() == want, i
+    handed = codec.decode_stats()["lz4_long_runs"]
+    runs_entries = int((b.classes == dg.RUNS).sum())
+    if mix == dg.RUNS:
+        assert handed == n, (handed, n)
+    elif mix == dg.TEXT:
+        assert handed == 0, handed
+    else:
+        assert runs_entries > 0 and handed == runs_entries, (handed, runs_entries)
+    assert codec.decode_stats()["lz4"] == n
+
+
 @pytest.mark.parametrize("size,level,n", [(262144, 3, 64), (1 << 20, 1, 24), (5000, 3, 200)])
 def test_zstd_two_stage_path(codec, size, level, n):
     """The Zstandard batch goes FSE pre-decode (k_zstd_fse, four streams per wave) -> literals + execution.  With the

@@ -118,7 +118,7 @@ def test_bench_gpus2_spawns_its_own_ranks():
     assert d["config"]["entries_total"] == 3000 and 0 < d["config"]["entries_per_gpu"] < 3000
     # every rank generated and uploaded ITS SLICE: rank 0's image is about half of what the two images hold together
     assert 0.3 < d["config"]["archive_image_bytes_this_rank"] / d["config"]["archive_image_bytes_all_ranks"] < 0.7
-    assert len(d["roofline"]["stage_ms"]) == 3 and d["roofline"]["stage_names"][0] == "k_lz4_wave"
+    assert len(d["roofline"]["stage_ms"]) == 3 and d["roofline"]["stage_names"][0].startswith("k_lz4_wave")
 
 
 def _write_worker(rank, world, port, q):

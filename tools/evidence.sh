@@ -53,9 +53,9 @@ d)
 d2)   # the same frames with every batch's work lists ordered (the default orders batches of >= 8192 entries only)
   ZPK_FUZZ_ORDER_MIN=1 timeout -k 10 1100 python3 tools/fuzz_gpu.py 400 13 all > $out/${tag}_fuzz_ordered.log 2>&1; echo "fuzz rc=$?"; tail -8 $out/${tag}_fuzz_ordered.log ;;
 e)
-  tools/r4_ab.sh $tag skip-tests 2>&1 | tee $out/${tag}_lz4_two_stage_ab.txt ;;
+  echo "part e (the LZ4 two-stage A/B of round 4) went with that path: tools/attic/r4_ab.sh" ;;
 g)
-  tools/r4_order.sh 2>&1 | tee $out/${tag}_order_ab.txt
+  tools/attic/r4_order.sh 2>&1 | tee $out/${tag}_order_ab.txt
   timeout -k 10 600 python3 tools/enc_ragged.py 30000 1 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_enc_ragged_order.txt
   timeout -k 10 400 python3 tools/big_entry_rate.py 256 16 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_entry_rate.txt ;;
 f)

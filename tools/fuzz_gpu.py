@@ -17,12 +17,6 @@ from tests._libs import oracle
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 codec = zpack_amd.Codec(0)
-# ZPK_FUZZ_LZ4_TWO = slot | window: every batch through the opt-in two-stage LZ4 path (stage 2 over the output slot / with the LDS window)
-if os.environ.get("ZPK_FUZZ_LZ4_TWO") in ("slot", "window"):
-    codec.set_option(zpack_amd.OPT_LZ4_TWO_STAGE_MIN, 0)
-    codec.set_option(zpack_amd.OPT_LZ4_TWO_STAGE_MAX_COMP, 4 << 20)
-    codec.set_option(zpack_amd.OPT_LZ4_EXEC_WINDOW, 1 if os.environ["ZPK_FUZZ_LZ4_TWO"] == "window" else 0)
-    print("two-stage LZ4 path:", os.environ["ZPK_FUZZ_LZ4_TWO"])
 if os.environ.get("ZPK_FUZZ_ORDER_MIN"):                       # 1: every batch runs its work lists largest entries first (default: batches of >= 8192 entries)
     codec.set_option(zpack_amd.OPT_ORDER_MIN, int(os.environ["ZPK_FUZZ_ORDER_MIN"]))
     print("work lists ordered from", os.environ["ZPK_FUZZ_ORDER_MIN"], "entries")

@@ -1,0 +1,30 @@
+#!/bin/bash
+# round 5, step H: k_lz4_scan + k_lz4_wave_h (chunks parsed from recorded segment entries): tests, then A/B scan on / off and against the round-4 kernels on one box
+out=gpurun_out/r05h; mkdir -p $out
+timeout -k 10 1100 python -m pytest tests/test_gpu_codec.py -m gpu -x -q > $out/pytest.log 2>&1; rc=$?
+tail -5 $out/pytest.log
+[ $rc -eq 0 ] || exit $rc
+one() {  # so label args...
+  so=$1; label=$2; shift 2
+  ZPACK_AMD_CODEC_SO=$so timeout -k 10 400 python bench.py "$@" --no-cpu > $out/$label.json 2> $out/$label.err || { tail -5 $out/$label.err; return 1; }
+  python3 - <<PY
+import json
+d=json.loads(open("$out/$label.json").read().strip().splitlines()[-1]); r=d["roofline"]
+print("$label: %.1f %s  %.3f ms/step  kernel %.3f ms %s runs-entries %s parity %s" % (d["value"], d["unit"], d["ms_per_step"], r["kernel_ms"], r.get("stage_ms"), r.get("lz4_entries_of_long_runs"), d["parity"]["all_ranks"]))
+PY
+}
+so_of() { [ $1 = new ] && echo $PWD/zpack_amd/libzpk_codec.so || echo $PWD/zpack_amd/dev/ab_$1.so; }
+for rep in 1 2; do
+  one $(so_of head) head_mix_$rep --steps 10 --warmup 3
+  ZPK_BENCH_LZ4_SCAN_MIN=0 one $(so_of new) noscan_mix_$rep --steps 10 --warmup 3
+  one $(so_of new) scan_mix_$rep --steps 10 --warmup 3
+  one $(so_of head) head_text_$rep --mix 0 --steps 8 --warmup 2
+  ZPK_BENCH_LZ4_SCAN_MIN=0 one $(so_of new) noscan_text_$rep --mix 0 --steps 8 --warmup 2
+  one $(so_of new) scan_text_$rep --mix 0 --steps 8 --warmup 2
+done
+for mix in 1 3; do
+  one $(so_of head) head_m$mix --mix $mix --steps 8 --warmup 2
+  one $(so_of new) scan_m$mix --mix $mix --steps 8 --warmup 2
+done
+one $(so_of head) head_c4 --workload c4_mixed --steps 3 --warmup 1
+one $(so_of new) scan_c4 --workload c4_mixed --steps 3 --warmup 1

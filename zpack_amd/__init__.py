@@ -17,8 +17,8 @@ ZPACK_SO = os.path.join(HERE, "libzpack_amd.so")
 METHOD_NONE, METHOD_ZSTD, METHOD_LZ4 = 0, 1, 2
 DF_SKIP_HASH = 1
 DF_GENERAL = 2
-K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_LZ4_PARSE, K_ENCODE = 0, 1, 2, 3, 4, 5, 6, 7
-OPT_LZ4_TWO_STAGE_MIN, OPT_LZ4_TWO_STAGE_MAX_COMP, OPT_DEV_LZ4_EXEC_PAD, OPT_LZ4_EXEC_WINDOW, OPT_ENC_SPLIT_MIN, OPT_DEC_SPLIT_MIN, OPT_ORDER_MIN, OPT_ORDER_FAST_LAST = 2, 3, 4, 5, 6, 7, 8, 9      # zpk_codec_set_option (include/zpack_codec.h)
+K_CLASSIFY, K_STORED, K_LZ4, K_ZSTD, K_ZSTD_FSE, K_PACK, K_ENCODE = 0, 1, 2, 3, 4, 5, 7
+OPT_ENC_SPLIT_MIN, OPT_DEC_SPLIT_MIN, OPT_ORDER_MIN, OPT_ORDER_FAST_LAST = 6, 7, 8, 9      # zpk_codec_set_option (include/zpack_codec.h)
 
 # zpk_decode_desc / zpk_decode_result / zpk_encode_desc / zpk_encode_result (include/zpack_codec.h)
 DECODE_DESC = np.dtype([("src_offset", "<u8"), ("comp_size", "<u8"), ("uncomp_size", "<u8"), ("expect_hash", "<u8"),
@@ -167,7 +167,7 @@ class Codec:
         self._chk(self.L.zpk_codec_decode_stats2(self.h, b), "decode_stats2")
         return dict(stored=a[0], zstd=a[1], lz4=a[2], zstd_two_stage=a[3], zstd_fused=a[4], fse_watchdog=a[5], fse_budget=a[6],
                     zstd_arena_refused=bool(a[7] >> 31), retried_lz4=b[0], retried_zstd=b[1],
-                    lz4_two_stage=b[2], lz4_two_stage_left=b[3], lz4_two_stage_taken=bool(b[4]),
+                    lz4_long_runs=b[3],
                     frame_parallel_entries=b[5], frame_parallel_frames=b[6])
 
     def debug_fetch(self, what, offset, count, dtype):

@@ -248,6 +248,8 @@ __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, bool on, u32 from
 }
 
 // one LZ4 block: src [ip, ip+C) -> dst [op, ...), cap = oend; dst_lo = lowest output address a match may reach
+// COOP: seq_exec.h (0 = k_lz4_wave's build, 2 = the build with grouped cooperative copies)
+template <int COOP = 2>
 __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* ip, u32 C, const u8* rd_hi,
                                      u8* dst_lo, u8*& op_io, u8* oend, int lane)
 {
@@ -367,7 +369,7 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
 #ifdef LZ4W_ABL_NOEXEC      // developer ablation (instruction counters only; the output is wrong): parse without the executor
             (void)dead; const int rc = D_OK; { const u32 xx = wave_scan_add(q.ll + q.ml); op += (u32)__builtin_amdgcn_readlane((int)xx, 63); }
 #else
-            const int rc = seq_exec_batch<true>(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
+            const int rc = seq_exec_batch<true, COOP>(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
 #endif
             if (rc != D_OK) { op_io = op; return rc; }
         }
@@ -380,101 +382,6 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
     return D_OK;
 }
 
-// ---- two-stage path (lz4_two.h): one block executed from PRE-PARSED sequence records -----------------------------------------
-// For large batches the token chains are walked by k_lz4_parse — one LANE per entry, the serial chain costs one wave instruction
-// per token step for 64 entries instead of ~350 per 64 tokens for the lane-parallel speculative walk above — and left in an arena as
-// 8-byte records: offset | literal position << 16 | literal length << 32 | match length << 48, all block-relative 16-bit values
-// (only frames of 64 KiB blocks take this path); the record with match length 0 is the block's last sequence.  This routine is
-// what is left of lz4_block_wave then: stage the compressed bytes for the literal reads, 64 records per seq_exec_batch.
-// ANY irregularity (a record that does not fit its block, the executor's malformed / does-not-fit verdicts, records that run out)
-// is returned as not-OK and the caller hands the entry to the general decoder above, which alone gives verdicts.
-struct Lz2Cursor {
-    const u64* rec; u32 left;                          // uniform: the entry's remaining records
-    // running XXH3 of the output (k_lz4_exec_g): every 1 KiB block is read back and hashed right behind the batch that completed it,
-    // while its lines are still in L2 — the hash pass at the end of the entry re-read all 64 KiB from memory (6.5 GB per 100 000
-    // entries, 13 % of the kernel's fabric traffic), long after the 4 KiB of L2 an entry in flight has were gone
-    const u8* hdst; u32 hpos, hash_blocks; Xxh3Lite xs;
-    __device__ __forceinline__ void hash_begin(const u8* dst, u64 uncomp_size, int lane)
-    {
-        hdst = dst; hpos = 0; hash_blocks = uncomp_size > 240 ? (u32)((uncomp_size - 1) >> 10) : 0u; xs.init(lane);
-    }
-    __device__ __forceinline__ void hash_upto(u64 produced, int lane)
-    {
-        while (hpos + 1024u <= produced && (hpos >> 10) < hash_blocks) {
-            const u128 v = ld128(hdst + hpos + 16u * (u32)lane);
-            xs.block(v, lane);
-            hpos += 1024u;
-        }
-    }
-};
-#define D_LZ2_INCONSISTENT (-9)
-
-__device__ inline int lz4_block_records(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* ip, u32 C, const u8* rd_hi,
-                                        u8* dst_lo, u8*& op_io, u8* oend, int lane, Lz2Cursor& cur)
-{
-    u8* op = op_io;
-    if (C == 0 || C > 65536u) return D_LZ2_INCONSISTENT;
-    u32 cbase = 0, cend = 0;                         // the stage holds block bytes [cbase, cend)
-    u64 r = (u32)lane < cur.left ? __builtin_nontemporal_load((const ZPK_GLOBAL u64*)(cur.rec + lane)) : 0ull;
-    for (;;) {
-        if (wd.expired()) return D_MALFORMED;
-        if (cur.left == 0) return D_LZ2_INCONSISTENT;                          // the records ran out in front of the block's end
-        const u32 avail = cur.left < (u32)WAVE ? cur.left : (u32)WAVE;
-        const u32 off = (u32)r & 0xFFFFu, lp = ((u32)r >> 16), ll = (u32)(r >> 32) & 0xFFFFu, ml = (u32)(r >> 48);
-        const bool in_list = (u32)lane < avail;
-        const u64 endm = __ballot(in_list && ml == 0);
-        const int cnt = endm ? __ffsll((long long)endm) : (int)avail;          // up to and including the block's last sequence
-        const bool finished = endm != 0;
-        cur.rec += cnt; cur.left -= (u32)cnt;
-        const u64 r_next = (u32)lane < cur.left ? __builtin_nontemporal_load((const ZPK_GLOBAL u64*)(cur.rec + lane)) : 0ull;      // in flight while this batch runs
-        const bool act = lane < cnt;
-        if (__ballot(act && lp + ll > C) != 0) return D_LZ2_INCONSISTENT;      // (memory safety of the literal reads; never, with our own parser)
-        // ---- the compressed bytes of the batch's literal runs, in LDS ----
-        const u32 first_lp = (u32)__builtin_amdgcn_readfirstlane((int)lp);
-        const u32 my_end = lp + (ll <= SEQ_OWN_MAX ? ll : 0u);                  // longer runs are copied from memory by the whole wave
-        const u32 need_end = (u32)__builtin_amdgcn_readlane((int)my_end, cnt - 1);
-        if (need_end > cend || cend == 0) {
-            cbase = first_lp;
-            const u32 nst = C - cbase < LZ4W_CHUNK + LZ4W_SLACK ? C - cbase : LZ4W_CHUNK + LZ4W_SLACK;
-            wave_mem_fence();
-            if (ip + cbase + ((nst + 15u) & ~15u) <= rd_hi) {
-                const u8* const g = ip + cbase + 16u * (u32)lane;
-                ZPK_LDS u8* const d0 = (ZPK_LDS u8*)sh.stage;
-                #pragma unroll
-                for (u32 i = 0; i < LZ4W_CHUNK + LZ4W_SLACK; i += WAVE * 16)
-                    if (i + 16u * (u32)lane < nst) __builtin_amdgcn_global_load_lds((const ZPK_GLOBAL u32*)(g + i), (ZPK_LDS u32*)(d0 + i), 16, 0, 2);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                for (u32 i = (u32)lane * 16; i < nst; i += WAVE * 16) {
-                    const u8* g = ip + cbase + i;
-                    if (i + 16 <= nst && g + 16 <= rd_hi) { u128 v = ld128(g); __builtin_memcpy(sh.stage + i, &v, 16); }
-                    else for (u32 k = i; k < nst && k < i + 16; k++) sh.stage[k] = ld8(ip + cbase + k);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            cend = cbase + nst;
-        }
-        SeqBatch q; q.lit = ip + lp; q.lit_lds = SEQ_NO_LDS; q.ll = act ? ll : 0u; q.ml = act ? ml : 0u; q.off = off; q.bad = 0;
-        if (act && ll <= SEQ_OWN_MAX && lp + ll <= cend) q.lit_lds = lp - cbase;
-        // the batch is assembled in LDS: in the part of the stage in front of its first literal run (dead by now) when that is the
-        // larger room, else in the list space the parse of the one-kernel path would have used
-        const u32 dead = first_lp - cbase;
-        const bool use_dead = dead > (u32)sizeof(sh.rec);
-        const int rc = seq_exec_batch<true>(q, cnt, op, oend, dst_lo, -1, lane, stt, to_lds(sh.stage),
-                                            use_dead ? to_lds_rw(sh.stage) : to_lds_rw((u8*)sh.rec), use_dead ? dead : (u32)sizeof(sh.rec));
-        if (rc != D_OK) { op_io = op; return rc; }
-        if (cur.hdst) { wave_mem_fence(); cur.hash_upto((u64)(op - cur.hdst), lane); }
-        if (finished) {
-            const u32 last_end = (u32)__builtin_amdgcn_readlane((int)(lp + ll), cnt - 1);
-            if (last_end != C) return D_LZ2_INCONSISTENT;                      // the chain did not end on the block's last byte
-            break;
-        }
-        r = r_next;
-    }
-    op_io = op;
-    return D_OK;
-}
-
 // whole frame.  src_lo/src_hi bound what may be READ (the archive image); all values uniform.
 // An entry may hold SEVERAL frames back to back: the reference calls LZ4F_decompress in a loop `while (avail_out > 0 && avail_in > 0)`
 // (lib/zpack_read.c:414-439) — a frame or skippable frame that completes returns 0 and the loop goes on with what is left of the
@@ -482,6 +389,7 @@ __device__ inline int lz4_block_records(Lz4WaveShared& sh, Watchdog& wd, SeqStat
 // otherwise FILE_INCOMPLETE / BUFFER_TOO_SMALL).  LZ4F looks at no header before it holds 7 bytes (fewer = "need more input"), then
 // checks the magic and FLG, waits for the header in full, then checks BD and the header checksum — in that order
 // (tests/golden/foreign_frames.json "lz4f:*" round-4 cases hold the reference's verdicts).
+template <int COOP = 2>
 __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* src, u64 src_size, const u8* src_lo, const u8* src_hi,
                                              u8* dst, u64 dst_cap, int lane, Lz4Resume* rs = nullptr)
 {
@@ -572,7 +480,7 @@ __device__ inline DecodeOut lz4f_decode_wave(Lz4WaveShared& sh, Watchdog& wd, Se
                 u8* bend = oend;
                 bool limited = false;
                 if ((u64)(oend - op) > bmax) { bend = op + bmax; limited = true; }
-                const int rc = lz4_block_wave(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane);
+                const int rc = lz4_block_wave<COOP>(sh, wd, stt, ip, (u32)bsz, src_hi, hist_lo, op, bend, lane);
                 if (rc == D_DST_FULL) {
                     if (limited) { r.rc = D_MALFORMED; return r; }
                     r.rc = D_DST_FULL; r.produced = (u64)(op - dst); return r;

@@ -152,6 +152,87 @@ __device__ __forceinline__ const u8* readlane_ptr(const u8* p, int k)
                        (u32)__builtin_amdgcn_readlane((int)(u32)(u64)p, k));
 }
 
+__device__ __forceinline__ u8* shfl_ptr(const u8* p, int k)
+{
+    return (u8*)(((u64)(u32)__shfl((int)(u32)((u64)p >> 32), k, 64) << 32) | (u32)__shfl((int)(u32)(u64)p, k, 64));
+}
+
+// Cooperative copies FOUR AT A TIME (round 5): every 16-lane row of the wave takes one run — lane k in `mask` holds a run of n bytes
+// to d from s (both global; no run's source overlaps any run's target of the same call), or, with `pat`, a PERIODIC run: its first
+// `period` bytes (1, 2, 4 or 8: a divisor of 16, so every 16-byte piece of the run is the same vector) are the low bytes of `pv` and
+// nothing is loaded at all.  A run used to be copied by the whole wave, one run after the other, each behind its own memory round
+// trip: an entry of byte runs (LZ4: literal + match at distance 1, ~400 sequences of ~165 bytes per 64 KiB) spent 0.8 ms in ~360
+// dependent round trips — as long as a text entry with 12 x the sequences (profiles/r04/r04_c2_per_class.txt: 614 vs 589 GiB/s).
+__device__ __forceinline__ void coop_copy_rows(u64 mask, u32 n, u8* d, const u8* s, bool pat, u32 period, u64 pv, int lane)
+{
+    const int g = lane >> 4;
+    const u32 sub16 = 16u * (u32)(lane & 15);
+    while (mask) {
+        int k[4];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { k[i] = mask ? __ffsll((long long)mask) - 1 : -1; if (mask) mask &= mask - 1; }
+        const int kk = g == 0 ? k[0] : (g == 1 ? k[1] : (g == 2 ? k[2] : k[3]));
+        const int from = kk < 0 ? lane : kk;
+        const u32 rn_any = (u32)__shfl((int)n, from, 64);          // (cross-lane reads stay outside divergent control flow: an inactive source lane reads as garbage)
+        const u32 rn = kk < 0 ? 0u : rn_any;
+        u8* const rd = shfl_ptr(d, from);
+        const u8* const rs = shfl_ptr(s, from);
+        const bool rpat = __shfl((int)(pat ? 1 : 0), from, 64) != 0;
+        const u32 rper = (u32)__shfl((int)period, from, 64);
+        u64 x = ((u64)(u32)__shfl((int)(u32)(pv >> 32), from, 64) << 32) | (u32)__shfl((int)(u32)pv, from, 64);
+        if (rper < 8u) { x &= 0xFFFFFFFFull; x |= x << 32; }
+        if (rper < 4u) { x &= 0x0000FFFF0000FFFFull; x |= x << 16; }
+        if (rper < 2u) { x &= 0x00FF00FF00FF00FFull; x |= x << 8; }
+        for (u32 c = sub16; __ballot(c < rn) != 0; c += 256u) {
+            if (c < rn) {
+                u128 v; v.lo = x; v.hi = x;
+                if (!rpat) v = gload_upto16(rs + c, rn - c);
+                gstore_upto16(rd + c, v, rn - c);
+            }
+        }
+    }
+}
+
+// The cooperative matches of one round (lanes in `cm`: ml > SEQ_OWN_MAX or offset < ml; all their sources are final).  Everything
+// here sits behind ONE uniform test of the round loop (`if (cm)`): on text a batch in eight has such a match, and a first version
+// that mixed the period loads into the round's common loads cost the common case 9 % (round 5, profiles/r05); as a real function
+// call (__noinline__) it cost 31 % — the call's register save area turned the kernel's 12 bytes of scratch into 96.
+//   * offset >= ml (a long plain copy) and offset < ml with a period of 1, 2, 4 or 8 bytes (byte runs, 16-bit patterns: the period
+//     is read by the match's own lane, one round trip for all of them, and the run is written from registers): FOUR AT A TIME,
+//     coop_copy_rows;
+//   * other periods: one match at a time by the whole wave — period >= 16 slab by slab (no lane reads what the same instruction
+//     writes), shorter periods byte by byte with a modulo.
+__device__ __forceinline__ void seq_coop_round(u64 cm, u32 ml, u32 off, u8* ms, const u8* srcp, const u8* oend, int lane)
+{
+    const bool mine = (cm >> lane) & 1;
+    const bool self_overlap = ml > off;
+    const bool pat = mine && self_overlap && off <= 8u && (off & (off - 1u)) == 0u;
+    Copy32 cb; cb.lo.lo = cb.lo.hi = cb.hi.lo = cb.hi.hi = 0;
+    if (pat) cb = gload_wide32(srcp, off, srcp + 16 <= oend);
+    const u64 gm = __ballot(mine && (pat || !self_overlap));
+    if (gm) coop_copy_rows(gm, ml, ms, srcp, pat, off, cb.lo.lo, lane);
+    u64 rest = cm & ~gm;
+    while (rest) {
+        const int k = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        const u32 n = (u32)__builtin_amdgcn_readlane((int)ml, k);
+        const u32 koff = (u32)__builtin_amdgcn_readlane((int)off, k);
+        u8* p = (u8*)readlane_ptr(ms, k);
+        const u8* m = readlane_ptr(srcp, k);                       // first period of match k
+        if (koff >= 16) {
+            for (u32 c = (u32)lane * 16; c < koff; c += WAVE * 16) gcopy_upto16(p + c, m + c, koff - c);
+            wave_mem_fence();
+            for (u32 base = koff; base < n; base += koff) {
+                const u32 slab = n - base < koff ? n - base : koff;
+                for (u32 c = (u32)lane * 16; c < slab; c += WAVE * 16) gcopy_upto16(p + base + c, p + base - koff + c, slab - c);
+                wave_mem_fence();
+            }
+        } else {
+            for (u32 c = lane; c < n; c += WAVE) st8(p + c, ld8(m + c % koff));
+        }
+    }
+}
+
 // developer aid: cycle accounting of the executor (kept in registers; written out only when asked)
 // compiled in only with -DZPK_STATS (the counters cost ~10 registers, i.e. a wave of occupancy per SIMD)
 #ifdef ZPK_STATS
@@ -262,7 +343,14 @@ __device__ __forceinline__ u64 seq_dependencies(bool has_match, u32 r_ms, u32 r_
 // ~17 partially filled ones.
 // NARROW_ONLY: the caller guarantees 31-bit positions and offsets (LZ4: 16-bit offsets, lengths clamped to 2^23), so only
 // the 32-bit dependency analysis is instantiated.
-template <bool NARROW_ONLY = false>
+// COOP (round 5): what a batch does with its cooperative pieces (matches longer than SEQ_OWN_MAX or feeding themselves, literal runs
+// longer than SEQ_OWN_MAX).  2 = four at a time, periodic runs from registers (coop_copy_rows, seq_coop_round): entries of byte runs
+// decode ~10 x faster.  0 = one at a time by the whole wave: the round-4 code, kept for k_lz4_wave ONLY — the mere presence of the
+// grouped code in that kernel, behind one uniform branch that text never takes, cost text 6 % (the compiler's code for the common
+// path changes: +3.7 % vector instructions, +18 % wait cycles; instruction-cache misses are nil), as a real call (__noinline__) 31 %:
+// profiles/r05/r05_coop_variants_ab.txt.  So k_classify sends the LZ4 entries that are mostly runs (compressed to less than an eighth)
+// to k_lz4_left, built with COOP = 2, and k_lz4_wave is the code it was.
+template <bool NARROW_ONLY = false, int COOP = 2>
 __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& op, u8* oend, const u8* dst_lo, int lit_rle, int lane,
                                               SeqStats& stt, lds_cp8 lit_stage = nullptr, lds_p8 asm_buf = nullptr, u32 asm_cap = 0)
 {
@@ -392,6 +480,10 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
         const Copy32 cb = gload_wide32(srcp, mn, srcp + 16 <= oend);
         gstore_wide32(o, ca, ln);
         gstore_wide32(ms, cb, mn);
+        if constexpr (COOP >= 2) {
+            const u64 lm = __ballot(long_lit);     // long runs: four at a time, a 16-lane row each (coop_copy_rows)
+            if (lm) coop_copy_rows(lm, ll, o, q.lit, false, 16u, 0ull, lane);
+        } else {
         u64 lm = __ballot(long_lit);
         while (lm) {                              // long runs: whole wave, 16 B per lane
             const int k = __ffsll((long long)lm) - 1;
@@ -400,6 +492,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
             u8* p = (u8*)readlane_ptr(o, k);
             const u8* s = readlane_ptr(q.lit, k);
             for (u32 c = (u32)lane * 16; c < n; c += WAVE * 16) gcopy_upto16(p + c, s + c, n - c);
+        }
         }
     }
     wave_mem_fence();
@@ -418,6 +511,11 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
             const Copy32 cb = gload_wide32(srcp, ml, srcp + 16 <= oend);
             gstore_wide32(ms, cb, ml);
         }
+        if constexpr (COOP >= 1) {
+            const u64 cm = __ballot(ready && coop);                // long or self-overlapping matches (seq_coop_round)
+            SEQ_STAT(stt.coops += (u32)__popcll(cm));
+            if (cm) seq_coop_round(cm, ml, q.off, ms, srcp, oend, lane);
+        } else {
         u64 cm = __ballot(ready && coop);
         SEQ_STAT(stt.coops += (u32)__popcll(cm));
         while (cm) {
@@ -429,7 +527,6 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
             const u8* m = readlane_ptr(srcp, k);                   // first period (or whole source) of match k
             if (koff >= n) { for (u32 c = (u32)lane * 16; c < n; c += WAVE * 16) gcopy_upto16(p + c, m + c, n - c); }
             else if (koff >= 16) {
-                // period >= 16: slab by slab, so that no lane reads what the same instruction writes
                 for (u32 c = (u32)lane * 16; c < koff; c += WAVE * 16) gcopy_upto16(p + c, m + c, koff - c);
                 wave_mem_fence();
                 for (u32 base = koff; base < n; base += koff) {
@@ -440,6 +537,7 @@ __device__ __forceinline__ int seq_exec_batch(const SeqBatch& q, int cnt, u8*& o
             } else {
                 for (u32 c = lane; c < n; c += WAVE) st8(p + c, ld8(m + c % koff));
             }
+        }
         }
         wave_mem_fence();
         done |= rmask;

@@ -26,7 +26,6 @@
 #include "xxh3_device.h"
 #include "xxh3_span.h"
 #include "lz4_wave.h"
-#include "lz4_two.h"
 #include "lx_ring.h"
 #ifndef LX_WAVES_PER_SIMD
 #define LX_WAVES_PER_SIMD 6
@@ -38,19 +37,17 @@
 using namespace zpk;
 
 // counters layout (u32): [0..3] count per work list, [4..7] dequeue head per list
-enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4, N_LISTS = 3 };
+enum { L_NONE = 0, L_ZSTD = 1, L_LZ4 = 2, L_COUNT = 4, N_LISTS = 3, L_LZ4_RUNS = 100 /* k_classify only: the LZ4 entries k_lz4_left takes (its list is slot N_LISTS + 2) */ };
 // [8] dequeue head of k_zstd_fse, [9] Zstandard entries finished on pre-decoded sequences, [10] finished by the fused decoder
 enum { C_ZSTD_TWO_STAGE = 9, C_ZSTD_FUSED = 10, C_EXEC_HEAD = 16, C_LEFT_COUNT = 17,
        C_RETRY_LZ4 = 18, C_RETRY_ZSTD = 19,     // entries whose decoder ran out of its time budget: decoded again by the retry launches
        C_RETRY_HEAD = 20,                       // dequeue head of the Zstandard retry launch
-       C_LZ4_LEFT = 21, C_LZ4_LEFT_HEAD = 22,   // two-stage LZ4 path: entries handed to the general decoder, its dequeue head
-       C_LZ4_TWO_OK = 23,                       // entries finished by the two-stage path
-       C_LZ4_BUMP = 24,                         // (two words, 8-byte aligned) record-arena allocator of k_lz4_parse
+       C_LZ4_LEFT = 21, C_LZ4_LEFT_HEAD = 22,   // LZ4 entries that are mostly runs (k_classify: compressed to less than 1/8): k_lz4_left's list, its dequeue head
        C_ENC_CLASS = 28,                        // (three words) encode batches: does the batch hold entries for k_encode<12> / <13> / <14> at all
        C_ORDER_SPAN = 26,                       // (two words) largest size class and largest 15 - class among the Zstandard / LZ4 entries
        C_ORDER = 32,                            // k_order_*: [2 lists][16 classes] entry counts, then the same again as fill cursors
        N_COUNTERS = 32 + 64 };
-enum { N_LISTS_ALLOC = N_LISTS + 5 };           // + the two retry lists + what the two-stage LZ4 path leaves to the general decoder + the two ordered lists
+enum { N_LISTS_ALLOC = N_LISTS + 5 };           // + the two retry lists + the LZ4 entries of long runs (k_lz4_left) + the two ordered lists
 
 // ------------------------------------------------------------------------------------ kernels
 
@@ -88,7 +85,7 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
         else list = L_NONE;
     }
     else if (d.method == ZPK_METHOD_ZSTD) list = L_ZSTD;
-    else if (d.method == ZPK_METHOD_LZ4) list = L_LZ4;
+    else if (d.method == ZPK_METHOD_LZ4) list = d.comp_size < (d.uncomp_size >> 3) ? L_LZ4_RUNS : L_LZ4;      // mostly runs: k_lz4_left's
     else r.status = R_COMP_METHOD_INVALID;                                     // :459
     // an entry that goes on a work list is not decoded yet: until its decoder writes the verdict the slot says so
     // (a decoder that never ran must not read as R_OK)
@@ -112,6 +109,16 @@ __global__ __launch_bounds__(256) void k_classify(const zpk_decode_desc* __restr
         if (lane == leader) base = atomicAdd(&counters[L], (u32)__popcll(m));
         base = (u32)__shfl((int)base, leader, 64);
         if (list == L) lists[(u64)L * list_stride + base + (u32)__popcll(m & ((1ull << lane) - 1))] = (u32)i;
+    }
+    {   // k_lz4_left's list: storage slot N_LISTS + 2, length in counters[C_LZ4_LEFT]
+        const u64 m = __ballot(list == L_LZ4_RUNS);
+        if (m != 0) {
+            const int leader = __ffsll((long long)m) - 1;
+            u32 base = 0;
+            if (lane == leader) base = atomicAdd(&counters[C_LZ4_LEFT], (u32)__popcll(m));
+            base = (u32)__shfl((int)base, leader, 64);
+            if (list == L_LZ4_RUNS) lists[(u64)(N_LISTS + 2) * list_stride + base + (u32)__popcll(m & ((1ull << lane) - 1))] = (u32)i;
+        }
     }
 }
 
@@ -268,6 +275,8 @@ __global__ __launch_bounds__(256) void k_stored(const u8* __restrict__ src, cons
 
 // one LZ4 entry, one wave.  retry_list != nullptr: a decode that ran out of its time budget is not reported — the entry goes on that
 // list (counters[C_RETRY_LZ4]) and k_lz4_retry decodes it again behind the batch with ZPK_WATCHDOG_RETRY_SCALE times the budget.
+// COOP: seq_exec.h — 0 in k_lz4_wave (the round-4 code, one cooperative piece at a time), 2 everywhere else (grouped cooperative copies).
+template <int COOP>
 __device__ __forceinline__ void lz4_entry_wave(Lz4WaveShared& shw, const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                const zpk_decode_desc* __restrict__ desc, u8* dst, zpk_decode_result* __restrict__ res,
                                                u32 e, u32* __restrict__ counters, u64* __restrict__ dbg, u32* __restrict__ retry_list,
@@ -279,7 +288,7 @@ __device__ __forceinline__ void lz4_entry_wave(Lz4WaveShared& shw, const u8* __r
     Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity), wd_scale);
     SeqStats stt = {};
     const u64 t_all = SEQ_T(); (void)t_all;
-    DecodeOut o = lz4f_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
+    DecodeOut o = lz4f_decode_wave<COOP>(shw, wd, stt, in, uni64(d.comp_size), read_lo, read_hi, out, uni64(d.dst_capacity), lane);
 #ifdef ZPK_STATS
     if (dbg && lane == 0) {
         u64* g = dbg + (u64)e * 8;
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(64, 8) void k_lz4_wave(const u8* __restrict__ src, 
     __shared__ Lz4WaveShared shw;
     u32 idx;
     if (my_slot(counters, L_LZ4, idx))
-        lz4_entry_wave(shw, src, read_lo, read_hi, desc, dst, res, uni(list[idx]), counters, dbg, retry_list, wd_scale, lane);
+        lz4_entry_wave<0>(shw, src, read_lo, read_hi, desc, dst, res, uni(list[idx]), counters, dbg, retry_list, wd_scale, lane);
 }
 
 // the entries k_lz4_wave gave up on (normally none): a small grid, ZPK_WATCHDOG_RETRY_SCALE times the budget, and now the verdict counts
@@ -337,116 +346,19 @@ __global__ __launch_bounds__(64, 8) void k_lz4_retry(const u8* __restrict__ src,
     __shared__ Lz4WaveShared shw;
     const u32 n_slots = uni(counters[C_RETRY_LZ4]);
     for (u32 idx = uni((u32)blockIdx.x); idx < n_slots; idx += gridDim.x)
-        lz4_entry_wave(shw, src, read_lo, read_hi, desc, dst, res, uni(list[idx]), counters, dbg, nullptr, (u32)ZPK_WATCHDOG_RETRY_SCALE, lane);
+        lz4_entry_wave<2>(shw, src, read_lo, read_hi, desc, dst, res, uni(list[idx]), counters, dbg, nullptr, (u32)ZPK_WATCHDOG_RETRY_SCALE, lane);
 }
 
-// ---- LZ4 in two stages (large batches; lz4_two.h) --------------------------------------------------------------------------------
-// k_lz4_parse: one LANE per work-list slot walks the entry's token chains and leaves 8-byte sequence records in the arena.
-// k_lz4_exec:  one WAVE per slot executes them (lz4_block_records) and verifies the XXH3 — it finishes an entry only when everything
-//              about it was regular: status OK, or FILE_HASH_MISMATCH for a complete decode whose checksum differs.
-// k_lz4_left:  every other entry (marked by the parser, or given up by the executor at the first irregularity) is decoded from
-//              scratch by the general one-wave decoder, so every other verdict, detail and produced size is always that decoder's.
-__global__ __launch_bounds__(64) void k_lz4_parse(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
-                                                  const zpk_decode_desc* __restrict__ desc, const u32* __restrict__ list,
-                                                  u32* __restrict__ counters, u64* __restrict__ arena, u64 arena_recs,
-                                                  Lz2Info* __restrict__ info, u32 max_comp)
-{
-    const int lane = lane_id();
-    __shared__ Lz2ParseShared sh;
-    const u32 nslots = uni(counters[L_LZ4]);
-    const u32 first = uni((u32)blockIdx.x * 64u);
-    if (first >= nslots) return;
-    lz4_parse_lanes(sh, src, read_lo, read_hi, desc, list, nslots, arena, arena_recs, (unsigned long long*)(counters + C_LZ4_BUMP), info,
-                    max_comp, first + (u32)lane, lane);
-}
-
-// stage 2 over the entry's output slot in memory (the window is HBM / L2): lz4_block_records
-__global__ __launch_bounds__(64, 7) void k_lz4_exec_g(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
-                                                  const zpk_decode_desc* __restrict__ desc, u8* dst,
-                                                  zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
-                                                  u32* __restrict__ counters, const u64* __restrict__ arena,
-                                                  const Lz2Info* __restrict__ info, u32* __restrict__ left_list)
-{
-    const int lane = lane_id();
-    __shared__ Lz4WaveShared shw;
-    u32 idx;
-    if (!my_slot(counters, L_LZ4, idx)) return;
-    const u32 e = uni(list[idx]);
-    const u32 rec_base = uni(info[idx].rec_base), nrec = uni(info[idx].nrec);
-    bool done = false;
-    if (!(nrec & LZ2_FALLBACK)) {
-        const zpk_decode_desc d = desc[e];
-        const u8* in = uni_ptr(src + d.src_offset);
-        u8* out = uni_ptr(dst + d.dst_offset);
-        const u64 usz = uni64(d.uncomp_size);
-        Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
-        SeqStats stt = {};
-        Lz2Cursor cur; cur.rec = arena + rec_base; cur.left = nrec;
-        cur.hash_begin(out, usz, lane);
-        const DecodeOut o = lz4f_slot_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_hi, out, uni64(d.dst_capacity), lane, cur);
-        if (o.rc == D_OK && cur.left == 0 && !wd.fired) {
-            u64 h;
-            wave_mem_fence();
-            if (usz > 240 && o.produced == usz) {
-                cur.hash_upto(usz, lane);                       // (blocks behind stored LZ4 blocks, which do not pass through the batch loop)
-                const u64 nb = cur.hash_blocks;
-                h = uni64(cur.xs.finish(out + (nb << 10), (u32)(((usz - 1) - (nb << 10)) >> 6), out + usz, usz, lane));
-            } else h = xxh3_64_wave(out, usz, lane);
-            const int status = (h == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH)) ? R_OK : R_FILE_HASH_MISMATCH;
-            lane0_guard();
-            if (lane == 0) { zpk_decode_result rr; rr.status = status; rr.detail = 0; rr.produced = o.produced; rr.hash = h; res[e] = rr; }
-            done = true;
-        }
-    }
-    lane0_guard();
-    if (lane == 0) {
-        if (done) atomicAdd(&counters[C_LZ4_TWO_OK], 1u);
-        else left_list[atomicAdd(&counters[C_LZ4_LEFT], 1u)] = e;
-    }
-}
-
-#ifndef LZ2_EXEC_WAVES
-#define LZ2_EXEC_WAVES 6
-#endif
-__global__ __launch_bounds__(64, LZ2_EXEC_WAVES) void k_lz4_exec(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
-                                                  const zpk_decode_desc* __restrict__ desc, u8* dst,
-                                                  zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
-                                                  u32* __restrict__ counters, const u64* __restrict__ arena,
-                                                  const Lz2Info* __restrict__ info, u32* __restrict__ left_list)
-{
-    const int lane = lane_id();
-    __shared__ Lz2ExecShared shw;
-    u32 idx;
-    if (!my_slot(counters, L_LZ4, idx)) return;
-    const u32 e = uni(list[idx]);
-    const u32 rec_base = uni(info[idx].rec_base), nrec = uni(info[idx].nrec);
-    bool done = false;
-    if (!(nrec & LZ2_FALLBACK)) {
-        const zpk_decode_desc d = desc[e];
-        const u8* in = uni_ptr(src + d.src_offset);
-        u8* out = uni_ptr(dst + d.dst_offset);
-        Watchdog wd; wd.arm(uni64(d.comp_size) + uni64(d.dst_capacity));
-        SeqStats stt = {};
-        Lz2Cursor cur; cur.rec = arena + rec_base; cur.left = nrec;
-        const LxResult r = lz4f_window_decode_wave(shw, wd, stt, in, uni64(d.comp_size), read_hi, out, uni64(d.dst_capacity), uni64(d.uncomp_size), lane, cur);
-        // a complete, regular decode is finished here whatever its checksum says (lib/zpack_read.c:466-468: FILE_HASH_MISMATCH leaves
-        // the data in the buffer; decoding the entry again could only find the same)
-        if (r.rc == LX_OK && !wd.fired) {
-            const int status = (r.hash == d.expect_hash || (d.flags & ZPK_DF_SKIP_HASH)) ? R_OK : R_FILE_HASH_MISMATCH;
-            lane0_guard();
-            if (lane == 0) { zpk_decode_result rr; rr.status = status; rr.detail = 0; rr.produced = r.produced; rr.hash = r.hash; res[e] = rr; }
-            done = true;
-        }
-    }
-    lane0_guard();
-    if (lane == 0) {
-        if (done) atomicAdd(&counters[C_LZ4_TWO_OK], 1u);
-        else left_list[atomicAdd(&counters[C_LZ4_LEFT], 1u)] = e;
-    }
-}
-
+// k_lz4_left: the LZ4 entries that are mostly RUNS — k_classify puts an entry compressed to less than an eighth of its size on this
+// list instead of k_lz4_wave's (byte runs, repeated blocks: matches longer than 32 bytes or feeding themselves; on the benchmark
+// corpus exactly the `runs` class) — decoded by the same one-wave decoder built with the grouped cooperative copies (seq_exec.h
+// COOP = 2): 614 -> ~2 000 GiB/s on such entries.  A persistent grid with an atomic dequeue, launched in FRONT of k_lz4_wave (a
+// launch behind it would be a serial tail); it leaves at once when the list is empty (text, records: always).
 #define LZ4_LEFT_GRID_MAX 8192u
-__global__ __launch_bounds__(64, 8) void k_lz4_left(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
+#ifndef LZ4_LEFT_WAVES
+#define LZ4_LEFT_WAVES 8
+#endif
+__global__ __launch_bounds__(64, LZ4_LEFT_WAVES) void k_lz4_left(const u8* __restrict__ src, const u8* read_lo, const u8* read_hi,
                                                   const zpk_decode_desc* __restrict__ desc, u8* dst,
                                                   zpk_decode_result* __restrict__ res, const u32* __restrict__ list,
                                                   u32* __restrict__ counters, u64* __restrict__ dbg, u32* __restrict__ retry_list, u32 wd_scale)
@@ -454,6 +366,7 @@ __global__ __launch_bounds__(64, 8) void k_lz4_left(const u8* __restrict__ src, 
     const int lane = lane_id();
     __shared__ Lz4WaveShared shw;
     const u32 n_slots = uni(counters[C_LZ4_LEFT]);
+    if (n_slots == 0) return;                      // (text, records: always — 8192 dequeues on one word are 0.1 ms by themselves)
     for (;;) {
         lane0_guard();
         u32 v = 0;
@@ -461,7 +374,7 @@ __global__ __launch_bounds__(64, 8) void k_lz4_left(const u8* __restrict__ src, 
         const u32 idx = uni(v);
         lane0_guard();
         if (idx >= n_slots) break;
-        lz4_entry_wave(shw, src, read_lo, read_hi, desc, dst, res, uni(list[idx]), counters, dbg, retry_list, wd_scale, lane);
+        lz4_entry_wave<2>(shw, src, read_lo, read_hi, desc, dst, res, uni(list[idx]), counters, dbg, retry_list, wd_scale, lane);
     }
 }
 
@@ -643,20 +556,9 @@ __global__ __launch_bounds__(256) void k_hash(const u8* __restrict__ src, const 
 
 // ------------------------------------------------------------------------------------ host side
 
-// The two-stage LZ4 path is OPT-IN (ZPK_OPT_LZ4_TWO_STAGE_MIN): measured on the headline workload (round 4, profiles/r04/
-// r04_lz4_two_stage_experiments.txt) it loses to the one-kernel decoder — 100 000 x 64 KiB: k_lz4_wave 9.7 ms; k_lz4_parse 5.1 ms +
-// stage 2 over the output slot 8.8-9.4 ms (39 % fewer vector instructions, but bound by 128-byte line fetches for far match sources:
-// 5.8 TB/s through the fabric) or + stage 2 with the LDS window 11.5 ms (fabric reads -57 %, but bound by LDS cycles).  It stays in
-// the build, parity-tested on every fixture, as the measured basis for the next step (a cheaper executor behind pre-parsed records).
 #define ZPK_DEC_SPLIT_MIN_DEFAULT (2ull << 20)
 #define ZPK_ENC_SPLIT_MIN_DEFAULT (2ull << 20)
 #define ZPK_ENC_PIECE (512u << 10)                 // = ZPK_CS_PIECE of the streaming writer
-#ifndef ZPK_LZ4_TWO_STAGE_MIN_DEFAULT
-#define ZPK_LZ4_TWO_STAGE_MIN_DEFAULT 0x7FFFFFFFu
-#endif
-#ifndef ZPK_LZ4_TWO_STAGE_MAX_COMP
-#define ZPK_LZ4_TWO_STAGE_MAX_COMP (96u << 10)
-#endif
 struct zpk_codec {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -676,6 +578,8 @@ struct zpk_codec {
     hipStream_t s_up = nullptr, s_dn = nullptr;  // host-pointer decode pipeline: upload / download streams beside `stream` (created on first use)
     hipStream_t s_side = nullptr;                // decode batches: the LZ4 kernel beside the Zstandard stages (low priority, created on first use)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t s_left = nullptr;                // decode batches: k_lz4_left (the LZ4 entries that are mostly runs) beside k_lz4_wave
+    hipEvent_t ev_lfork = nullptr, ev_ljoin = nullptr;
     volatile u32* h_seen = nullptr;              // pinned: the work-list counts of an earlier device batch (what the next one probably holds)
     hipEvent_t pipe_ev[2 * 64] = {};             // per piece: uploaded, decoded
     u8*  d_dst = nullptr;        u64 dst_cap = 0;
@@ -696,13 +600,6 @@ struct zpk_codec {
     u64* d_zarena = nullptr;     u64 zarena_cap = 0;   // decoder: pre-decoded Zstandard sequences, laid out like dst (zstd_fse4.h)
     u32* d_zstate = nullptr;     u64 zstate_cap = 0;   // decoder: per entry, 1 = its sequences are in the arena
     int lz4_hint = -1;           // host path: does the batch hold an LZ4 entry?  -1 = unknown (device path)
-    u64* d_lz2arena = nullptr;   u64 lz2arena_cap = 0; // decoder: pre-parsed LZ4 sequence records (lz4_two.h)
-    void* d_lz2info = nullptr;   u64 lz2info_cap = 0;  // decoder: per work-list slot, where its records are
-    u32 lz4_two_min = ZPK_LZ4_TWO_STAGE_MIN_DEFAULT;   // batches of at least this many entries take the two-stage LZ4 path
-    u32 lz4_two_max_comp = ZPK_LZ4_TWO_STAGE_MAX_COMP; // ... for entries of at most this many compressed bytes (one lane walks one entry)
-    int lz4_two_last = 0;        // the last decode batch took it
-    int lz4_exec_window = 0;     // stage 2 assembles the output in an LDS window (k_lz4_exec) instead of in the output slot (k_lz4_exec_g)
-    u32 lz4_exec_pad = 0;        // developer aid (ZPK_OPT_DEV_LZ4_EXEC_PAD): extra dynamic LDS per k_lz4_exec workgroup = fewer entries in flight
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t kev[ZPK_K_COUNT][2] = {};
     int profiling = 0;
@@ -799,10 +696,13 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->s_side) (void)hipStreamDestroy(c->s_side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->s_left) (void)hipStreamDestroy(c->s_left);
+    if (c->ev_lfork) (void)hipEventDestroy(c->ev_lfork);
+    if (c->ev_ljoin) (void)hipEventDestroy(c->ev_ljoin);
     if (c->s_up) (void)hipStreamDestroy(c->s_up);
     if (c->s_dn) (void)hipStreamDestroy(c->s_dn);
     for (int k = 0; k < 2 * 64; k++) if (c->pipe_ev[k]) (void)hipEventDestroy(c->pipe_ev[k]);
-    (void)hipFree(c->d_lz2arena); (void)hipFree(c->d_lz2info); (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_pack); (void)hipFree(c->d_packed); (void)hipFree(c->d_packoff); (void)hipFree(c->d_xpart);
+    (void)hipFree(c->d_dbg); (void)hipFree(c->d_seq); (void)hipFree(c->d_zarena); (void)hipFree(c->d_zstate); (void)hipFree(c->d_pack); (void)hipFree(c->d_packed); (void)hipFree(c->d_packoff); (void)hipFree(c->d_xpart);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < ZPK_K_COUNT; i++) for (int j = 0; j < 2; j++) if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
@@ -823,8 +723,8 @@ void zpk_codec_reset(zpk_codec* c)
     // a context keeps its grown staging between batches (the next batch of that size starts at once); a reset gives the large pieces
     // back — a process that holds many readers can bound what each one retains (zpack_reset_reader_dctx / zpack_reset_writer_cctx)
     const u64 keep = 64ull << 20;
-    void** bufs[] = { (void**)&c->d_src, (void**)&c->d_dst, (void**)&c->d_zarena, (void**)&c->d_lit, (void**)&c->d_lz2arena };
-    u64* caps[] = { &c->src_cap, &c->dst_cap, &c->zarena_cap, &c->lit_cap, &c->lz2arena_cap };
+    void** bufs[] = { (void**)&c->d_src, (void**)&c->d_dst, (void**)&c->d_zarena, (void**)&c->d_lit };
+    u64* caps[] = { &c->src_cap, &c->dst_cap, &c->zarena_cap, &c->lit_cap };
     for (int i = 0; i < 5; i++) if (*bufs[i] && *caps[i] > keep) { (void)hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
 }
 const char* zpk_codec_last_error(const zpk_codec* c) { return c ? c->err : "no codec"; }
@@ -926,7 +826,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     // workgroup per entry, and 100 000 EMPTY workgroups trickling through at low priority beside the pre-decode stage cost it 15 ms
     // (71.9 -> 87.6 ms).  So the codec looks at the work-list counts of the batch BEFORE (copied to pinned memory behind every batch,
     // no synchronisation): both methods there, or nothing known yet -> side stream; a codec fed batches of one method stays on one stream.
-    if (!c->h_seen && hipHostMalloc((void**)&c->h_seen, 64, hipHostMallocDefault) == hipSuccess) { c->h_seen[L_NONE] = 0; c->h_seen[L_ZSTD] = 1; c->h_seen[L_LZ4] = 1; }
+    if (!c->h_seen && hipHostMalloc((void**)&c->h_seen, 64, hipHostMallocDefault) == hipSuccess) { c->h_seen[L_NONE] = 0; c->h_seen[L_ZSTD] = 1; c->h_seen[L_LZ4] = 1; c->h_seen[8] = 1; }
     const bool both_seen = c->zstd_hint >= 0 /* the host path knows */ || (c->h_seen && c->h_seen[L_ZSTD] != 0 && c->h_seen[L_LZ4] != 0);
     if (maybe_lz4 && maybe_zstd && both_seen && !(skip & 6)) {
         int lo_prio = 0, hi_prio = 0;
@@ -938,39 +838,28 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
             hipStreamWaitEvent(c->s_side, c->ev_fork, 0) == hipSuccess) sl = c->s_side;
     }
 #endif
-    // Large batches: the token chains one LANE per entry (k_lz4_parse), the execution one wave per entry from the records
-    // (k_lz4_exec), the general decoder for whatever the two did not finish (lz4_two.h).  Record arena: fewer than one record
-    // per 3 compressed bytes; without it (allocation refused) the batch takes the one-kernel path.
-    bool lz4_two = maybe_lz4 && n >= c->lz4_two_min && read_hi > read_lo;
-    u64 arena_recs = 0;
-    if (lz4_two) {
-        arena_recs = (u64)(read_hi - read_lo) / 3 + 2 * n + 64;
-        if (arena_recs > 0xFFFFFFF0ull) arena_recs = 0xFFFFFFF0ull;      // (32-bit record indices; entries beyond it stay with the general decoder)
-        if (grow(c, (void**)&c->d_lz2arena, &c->lz2arena_cap, arena_recs * 8) != ZPK_OK ||
-            grow(c, &c->d_lz2info, &c->lz2info_cap, n * sizeof(Lz2Info)) != ZPK_OK) { lz4_two = false; c->err[0] = 0; }
-    }
-    c->lz4_two_last = lz4_two ? 1 : 0;
     auto launch_lz4 = [&]() {
         if (c->profiling) (void)hipEventRecord(c->kev[ZPK_K_LZ4][0], sl);
-        if (!(skip & 2) && maybe_lz4 && lz4_two) {
-            const u32* const l4 = lz4_list;
-            if (c->profiling) (void)hipEventRecord(c->kev[ZPK_K_LZ4_PARSE][0], sl);
-            hipLaunchKernelGGL(k_lz4_parse, dim3((u32)((n + 63) / 64)), dim3(64), 0, sl, src, read_lo, read_hi, desc, l4, c->d_counters,
-                               c->d_lz2arena, arena_recs, (Lz2Info*)c->d_lz2info, c->lz4_two_max_comp);
-            if (c->profiling) (void)hipEventRecord(c->kev[ZPK_K_LZ4_PARSE][1], sl);
-            if (c->lz4_exec_window)
-                hipLaunchKernelGGL(k_lz4_exec, dim3((u32)n), dim3(64), c->lz4_exec_pad, sl, src, read_lo, read_hi, desc, dst, res, l4, c->d_counters,
-                                   (const u64*)c->d_lz2arena, (const Lz2Info*)c->d_lz2info, left_lz4);
-            else
-                hipLaunchKernelGGL(k_lz4_exec_g, dim3((u32)n), dim3(64), c->lz4_exec_pad, sl, src, read_lo, read_hi, desc, dst, res, l4, c->d_counters,
-                                   (const u64*)c->d_lz2arena, (const Lz2Info*)c->d_lz2info, left_lz4);
-            hipLaunchKernelGGL(k_lz4_left, dim3((u32)(n < LZ4_LEFT_GRID_MAX ? n : LZ4_LEFT_GRID_MAX)), dim3(64), 0, sl, src, read_lo, read_hi, desc, dst, res,
+        if (!(skip & 2) && maybe_lz4) {
+            // The entries that are mostly runs (k_classify's second LZ4 list; none on text) by the build with the grouped cooperative copies,
+            // BESIDE k_lz4_wave on a stream of its own: in front of it or behind it the few thousand of them were a serial stretch of one
+            // entry's latency (0.4 ms of a 10 ms batch) with the chip nearly idle.
+            hipStream_t sx = sl;
+            // (a small batch is latency, not throughput: no second stream; neither when the batch BEFORE had no such entry — then the launch
+            // is an empty grid in front of k_lz4_wave, and a batch that does have some pays the serial stretch once)
+            if (n >= 4096 && c->h_seen && c->h_seen[8] != 0) {
+            if (!c->s_left && hipStreamCreateWithFlags(&c->s_left, hipStreamNonBlocking) != hipSuccess) c->s_left = nullptr;
+            if (!c->ev_lfork && hipEventCreateWithFlags(&c->ev_lfork, hipEventDisableTiming) != hipSuccess) c->ev_lfork = nullptr;
+            if (!c->ev_ljoin && hipEventCreateWithFlags(&c->ev_ljoin, hipEventDisableTiming) != hipSuccess) c->ev_ljoin = nullptr;
+            if (c->s_left && c->ev_lfork && c->ev_ljoin && hipEventRecord(c->ev_lfork, sl) == hipSuccess &&
+                hipStreamWaitEvent(c->s_left, c->ev_lfork, 0) == hipSuccess) sx = c->s_left;
+            }
+            hipLaunchKernelGGL(k_lz4_left, dim3((u32)(n < LZ4_LEFT_GRID_MAX ? n : LZ4_LEFT_GRID_MAX)), dim3(64), 0, sx, src, read_lo, read_hi, desc, dst, res,
                                (const u32*)left_lz4, c->d_counters, c->d_dbg, retry_lz4, wd_scale);
-            hipLaunchKernelGGL(k_lz4_retry, dim3((u32)(n < 256 ? n : 256)), dim3(64), 0, sl, src, read_lo, read_hi, desc, dst, res,
-                               (const u32*)retry_lz4, c->d_counters, c->d_dbg);
-        } else if (!(skip & 2) && maybe_lz4) {
             hipLaunchKernelGGL(k_lz4_wave, dim3((u32)n), dim3(64), 0, sl, src, read_lo, read_hi, desc, dst, res,
                                lz4_list, c->d_counters, c->d_dbg, retry_lz4 ZPK_WD_ARG);
+            if (sx != sl && (hipEventRecord(c->ev_ljoin, sx) != hipSuccess || hipStreamWaitEvent(sl, c->ev_ljoin, 0) != hipSuccess))
+                (void)hipStreamSynchronize(sx);
             // entries whose decoder ran out of its time budget: again, with ZPK_WATCHDOG_RETRY_SCALE times the budget (a small grid
             // that leaves at once when the list is empty — the normal case)
             hipLaunchKernelGGL(k_lz4_retry, dim3((u32)(n < 256 ? n : 256)), dim3(64), 0, sl, src, read_lo, read_hi, desc, dst, res,
@@ -1028,6 +917,7 @@ static int decode_launch(zpk_codec* c, const u8* src, u64 src_size, const u8* re
     }
     ZPK_TRACE_STEP("retry");
     if (c->h_seen && c->zstd_hint < 0) (void)hipMemcpyAsync((void*)c->h_seen, c->d_counters, N_LISTS * sizeof(u32), hipMemcpyDeviceToHost, st);
+    if (c->h_seen) (void)hipMemcpyAsync((void*)(c->h_seen + 8), c->d_counters + C_LZ4_LEFT, sizeof(u32), hipMemcpyDeviceToHost, st);      // did this batch have LZ4 entries of runs?
     HIPCHK(c, hipGetLastError());
     return ZPK_OK;
 }
@@ -1726,7 +1616,7 @@ int zpk_codec_decode_stats(zpk_codec* c, uint32_t out[8])
     u32 h[N_COUNTERS];
     HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     if (c->totals_valid) memcpy(h, c->host_totals, sizeof(h));          // a pipelined host batch: the sum over its launches
-    out[0] = h[L_NONE]; out[1] = h[L_ZSTD]; out[2] = h[L_LZ4]; out[3] = h[C_ZSTD_TWO_STAGE]; out[4] = h[C_ZSTD_FUSED];
+    out[0] = h[L_NONE]; out[1] = h[L_ZSTD]; out[2] = h[L_LZ4] + h[C_LZ4_LEFT] /* both LZ4 lists */; out[3] = h[C_ZSTD_TWO_STAGE]; out[4] = h[C_ZSTD_FUSED];
     out[5] = h[ZF_WATCHDOG_WORD]; out[6] = h[ZF_WATCHDOG_WORD + 1]; out[7] = h[13];
     if (c->fell_back_fused) out[7] |= 0x80000000u;          // the batch could not get its sequence arena: fused decoder only
     ZPK_DEV(if (getenv("ZPK_TRACE")) fprintf(stderr, "[zpk] fse marked %u, pass-0 failures %u, last failure status/rc %08x\n", h[13], h[14], h[15]);)
@@ -1746,7 +1636,7 @@ int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
     if (c->totals_valid) memcpy(h, c->host_totals, sizeof(h));
     memset(out, 0, 16 * sizeof(uint32_t));
     out[0] = h[C_RETRY_LZ4]; out[1] = h[C_RETRY_ZSTD];
-    out[2] = h[C_LZ4_TWO_OK]; out[3] = h[C_LZ4_LEFT]; out[4] = (u32)c->lz4_two_last;
+    out[2] = 0; out[3] = h[C_LZ4_LEFT]; out[4] = 0;      // [3]: LZ4 entries that are mostly runs, decoded by k_lz4_left (the two-stage path of round 4 is gone: [2], [4] read 0)
     out[5] = c->big_last[0]; out[6] = c->big_last[1];
     return ZPK_OK;
 }
@@ -1769,14 +1659,10 @@ int zpk_codec_set_option(zpk_codec* c, int option, int value)
 {
     if (!c) return ZPK_E_INVALID;
     CodecLock lk(c);
-    if (option == ZPK_OPT_LZ4_TWO_STAGE_MIN) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_min = (u32)value; return ZPK_OK; }
-    if (option == ZPK_OPT_LZ4_EXEC_WINDOW) { c->lz4_exec_window = value ? 1 : 0; return ZPK_OK; }
-    if (option == ZPK_OPT_DEV_LZ4_EXEC_PAD) { if (value < 0 || value > (120 << 10)) return ZPK_E_INVALID; c->lz4_exec_pad = (u32)value; return ZPK_OK; }
     if (option == ZPK_OPT_ORDER_FAST_LAST) { c->order_fast_last = value ? 1 : 0; return ZPK_OK; }
     if (option == ZPK_OPT_ORDER_MIN) { if (value < 0) return ZPK_E_INVALID; c->order_min = c->enc_order_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_DEC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->dec_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
     if (option == ZPK_OPT_ENC_SPLIT_MIN) { if (value < 0) return ZPK_E_INVALID; c->enc_split_min = value == 0 ? ~0ull : (u64)value; return ZPK_OK; }
-    if (option == ZPK_OPT_LZ4_TWO_STAGE_MAX_COMP) { if (value < 0) return ZPK_E_INVALID; c->lz4_two_max_comp = (u32)value; return ZPK_OK; }
     return ZPK_E_INVALID;
 }
 
