@@ -105,10 +105,79 @@ def test_big_entries_frame_parallel_equals_one_wave(codec):
     codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
     r2, out2 = codec.decode_batch_host(arc2, _descs(offs2, cs2, sizes[:5], res2["hash"], methods[:5]))
     st = codec.decode_stats()
-    assert (r2["status"] == 0).all() and st["frame_parallel_entries"] == 1          # (only the stored entry: slices need no frames)
+    # (the stored entry: slices need no frames; and the two LZ4 entries of >= 2 MiB, ONE frame each: block-parallel, lz4_pj.h)
+    assert (r2["status"] == 0).all() and st["frame_parallel_entries"] == 3, st
     for i in range(5):
         assert np.array_equal(out2[i], plains[i])
     codec.set_option(OPT_ENC_SPLIT_MIN, 2 * M)
+
+
+@pytest.mark.parametrize("cls", [dg.TEXT, dg.RECORDS, dg.RANDOM, dg.RUNS])
+def test_one_large_lz4_frame_is_decoded_block_parallel(codec, cls):
+    """What the reference writer produces for a large LZ4 entry is ONE frame of linked 64 KiB blocks (lib/zpack_write.c:204-210).  The
+    host read path parses its blocks side by side and resolves every output byte to the literal it copies by pointer doubling
+    (lz4_pj.h): frames made by liblz4 (the reference's call sequence) of every corpus class — bytes equal the plaintext and the
+    one-wave decoder's, the hash is the real xxHash's, the counters say that the block-parallel path ran."""
+    sizes = [2 * M, 5 * M + 12345, 9 * M + 1]
+    plains = [dg.fill(cls, 77, i, n) for i, n in enumerate(sizes)]
+    pay = [np.frombuffer(dg.compress(METHOD_LZ4, 0, p), dtype=np.uint8) for p in plains]
+    want = [dg.xxh3(p) for p in plains]
+    arc, offs, cs = _image(pay)
+    d = _descs(offs, cs, sizes, want, [(METHOD_LZ4, 0)] * len(sizes))
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    r1, out1 = codec.decode_batch_host(arc, d)
+    st = codec.decode_stats()
+    assert st["frame_parallel_entries"] == len(sizes), st
+    codec.set_option(OPT_DEC_SPLIT_MIN, 0)
+    r0, out0 = codec.decode_batch_host(arc, d)
+    assert codec.decode_stats()["frame_parallel_entries"] == 0
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    for r in (r0, r1):
+        assert (r["status"] == 0).all() and [int(h) for h in r["hash"]] == want and [int(x) for x in r["produced"]] == sizes, r
+    for i, p in enumerate(plains):
+        assert np.array_equal(out1[i], p) and np.array_equal(out0[i], p), i
+
+
+def test_one_large_lz4_frame_damaged_gets_the_one_wave_verdict(codec):
+    """The block-parallel reader finishes an entry only when everything about it was regular; a flipped byte, a short or long comp_size,
+    a wrong hash, a small capacity, a frame with checksums or a content size that disagrees: status, produced and bytes are those of
+    the one-wave decoder (= the oracle's = the compiled reference's)."""
+    o = oracle()
+    rng = np.random.default_rng(17)
+    plain = dg.fill(dg.TEXT, 91, 0, 3 * M + 999)
+    good = np.frombuffer(dg.compress(METHOD_LZ4, 0, plain), dtype=np.uint8).copy()
+    h = dg.xxh3(plain)
+    variants = []
+    for k in range(int(os.environ.get("ZPK_BIG_FUZZ_ITERS", "12"))):
+        b = good.copy(); at = int(rng.integers(0, len(b))); b[at] ^= 0x41
+        variants.append(("flip@%d" % at, b, len(b), h, len(plain)))
+    b = good.copy(); b[4] ^= 0x20                                            # independent blocks claimed (the header checksum then fails)
+    variants.append(("flg", b, len(b), h, len(plain)))
+    variants.append(("comp_size - 5", good, len(good) - 5, h, len(plain)))
+    variants.append(("comp_size + 3", np.concatenate([good, np.zeros(8, np.uint8)]), len(good) + 3, h, len(plain)))
+    variants.append(("hash", good, len(good), h ^ 1, len(plain)))
+    variants.append(("capacity", good, len(good), h, len(plain) - 1))
+    variants.append(("intact", good, len(good), h, len(plain)))
+    for label, payload, csize, eh, cap in variants:
+        arc, offs, _ = _image([payload])
+        d = _descs(offs, [csize], [len(plain)], [eh], [(METHOD_LZ4, 0)])
+        d["dst_capacity"] = cap
+        codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+        r1, out1 = codec.decode_batch_host(arc, d)
+        par = codec.decode_stats()["frame_parallel_entries"]
+        codec.set_option(OPT_DEC_SPLIT_MIN, 0)
+        r0, out0 = codec.decode_batch_host(arc, d)
+        assert int(r1["status"][0]) == int(r0["status"][0]), (label, r1, r0)
+        if r0["status"][0] == 0:
+            assert r1["hash"][0] == r0["hash"][0] and r1["produced"][0] == r0["produced"][0], label
+            assert np.array_equal(out1[0], out0[0]), label
+        if label == "intact":
+            assert par == 1 and r1["status"][0] == 0 and np.array_equal(out1[0], plain)
+        if label == "hash":
+            assert par == 1 and r1["status"][0] == 15 and np.array_equal(out1[0][:len(plain)], plain), label
+        rc, out, got, hh = o.entry_decode(arc.tobytes(), int(offs[0]), csize, len(plain), eh, METHOD_LZ4, cap)
+        assert rc == int(r1["status"][0]), (label, rc, r1)
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
 
 
 def test_big_entry_damage_gets_the_one_wave_verdict(codec):

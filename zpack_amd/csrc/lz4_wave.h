@@ -247,11 +247,15 @@ __device__ __forceinline__ Lz4Walk lz4_walk(const Lz4Bytes& B, bool on, u32 from
     return w;
 }
 
+// EMIT (lz4_pj.h, the block-parallel decoder of large frames): the block is only PARSED — every batch of up to 64 sequences goes to
+// `emit(q, cnt, literal position in the block)` instead of the executor, nothing is read from or written to the output.
+struct Lz4NoEmit { __device__ __forceinline__ int operator()(const SeqBatch&, int, u32) const { return D_OK; } };
+
 // one LZ4 block: src [ip, ip+C) -> dst [op, ...), cap = oend; dst_lo = lowest output address a match may reach
 // COOP: seq_exec.h (0 = k_lz4_wave's build, 2 = the build with grouped cooperative copies)
-template <int COOP = 2>
+template <int COOP = 2, bool EMIT = false, class Emit = Lz4NoEmit>
 __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& stt, const u8* ip, u32 C, const u8* rd_hi,
-                                     u8* dst_lo, u8*& op_io, u8* oend, int lane)
+                                     u8* dst_lo, u8*& op_io, u8* oend, int lane, Emit emit = Emit())
 {
     u8* op = op_io;
     if (C == 0) return D_MALFORMED;
@@ -369,7 +373,9 @@ __device__ inline int lz4_block_wave(Lz4WaveShared& sh, Watchdog& wd, SeqStats& 
 #ifdef LZ4W_ABL_NOEXEC      // developer ablation (instruction counters only; the output is wrong): parse without the executor
             (void)dead; const int rc = D_OK; { const u32 xx = wave_scan_add(q.ll + q.ml); op += (u32)__builtin_amdgcn_readlane((int)xx, 63); }
 #else
-            const int rc = seq_exec_batch<true, COOP>(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
+            int rc;
+            if constexpr (EMIT) { (void)dead; rc = emit(q, cnt, (u32)(q.lit - ip)); }
+            else rc = seq_exec_batch<true, COOP>(q, cnt, op, oend, dst_lo, -1, lane, stt, B.S, to_lds_rw(sh.stage), dead);
 #endif
             if (rc != D_OK) { op_io = op; return rc; }
         }

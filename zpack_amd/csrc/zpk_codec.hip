@@ -33,6 +33,7 @@
 #include "zstd_wg.h"
 #include "zstd_fse4.h"
 #include "zstd_ring.h"
+#include "lz4_pj.h"
 
 using namespace zpk;
 
@@ -578,6 +579,11 @@ struct zpk_codec {
     hipStream_t s_up = nullptr, s_dn = nullptr;  // host-pointer decode pipeline: upload / download streams beside `stream` (created on first use)
     hipStream_t s_side = nullptr;                // decode batches: the LZ4 kernel beside the Zstandard stages (low priority, created on first use)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void* d_pj_blocks = nullptr; u64 pj_blocks_cap = 0; // large single LZ4 frames (lz4_pj.h): block table, sequence records, start masks, byte references, flags
+    void* d_pj_recs = nullptr;   u64 pj_recs_cap = 0;
+    void* d_pj_masks = nullptr;  u64 pj_masks_cap = 0;
+    void* d_pj_S = nullptr;      u64 pj_S_cap = 0;
+    u32*  d_pj_flags = nullptr;
     hipStream_t s_left = nullptr;                // decode batches: k_lz4_left (the LZ4 entries that are mostly runs) beside k_lz4_wave
     hipEvent_t ev_lfork = nullptr, ev_ljoin = nullptr;
     volatile u32* h_seen = nullptr;              // pinned: the work-list counts of an earlier device batch (what the next one probably holds)
@@ -595,6 +601,7 @@ struct zpk_codec {
     int  order_fast_last = 1;                          // ZPK_OPT_ORDER_FAST_LAST: a batch of one size class runs its incompressible entries last
     u64  order_min = 8192;                             // ZPK_OPT_ORDER_MIN: decode batches of at least this many entries run their work lists largest entries first
     u64  dec_split_min = ZPK_DEC_SPLIT_MIN_DEFAULT;    // ZPK_OPT_DEC_SPLIT_MIN: entries of at least this many bytes that ARE sequences of frames are decoded frame-parallel
+    u32  pj_last_rounds = 0;                           // lz4_pj.h: pointer-doubling rounds of the most recent large LZ4 frame
     u32  big_last[2] = {0, 0};                         // host decode path, most recent call: entries decoded frame-parallel, their frames
     u64  enc_split_min = ZPK_ENC_SPLIT_MIN_DEFAULT;    // ZPK_OPT_ENC_SPLIT_MIN: entries of at least this many bytes are written as a sequence of frames
     u64* d_zarena = nullptr;     u64 zarena_cap = 0;   // decoder: pre-decoded Zstandard sequences, laid out like dst (zstd_fse4.h)
@@ -696,6 +703,7 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->s_side) (void)hipStreamDestroy(c->s_side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    (void)hipFree(c->d_pj_blocks); (void)hipFree(c->d_pj_recs); (void)hipFree(c->d_pj_masks); (void)hipFree(c->d_pj_S); (void)hipFree(c->d_pj_flags);
     if (c->s_left) (void)hipStreamDestroy(c->s_left);
     if (c->ev_lfork) (void)hipEventDestroy(c->ev_lfork);
     if (c->ev_ljoin) (void)hipEventDestroy(c->ev_ljoin);
@@ -1360,6 +1368,109 @@ other:
     return false;
 }
 
+// ---- ONE LARGE LZ4 FRAME (what the reference writer produces for any large entry: lib/zpack_write.c:204-210), block-parallel: lz4_pj.h ----
+// XXH32 of a frame descriptor (2 .. 14 bytes; xxHash specification, inputs shorter than 16 bytes): the header checksum byte is (h >> 8) & 0xFF
+static u32 host_xxh32_small(const u8* p, u32 len)
+{
+    const u32 P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    (void)P1; (void)P2;
+    u32 h = P5 + len;
+    u32 i = 0;
+    for (; i + 4 <= len; i += 4) { h += hrd32(p + i) * P3; h = ((h << 17) | (h >> 15)) * P4; }
+    for (; i < len; i++) { h += (u32)p[i] * P5; h = ((h << 11) | (h >> 21)) * P1; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+#ifndef ZPK_PJ_MIN_BLOCKS
+#define ZPK_PJ_MIN_BLOCKS 8u
+#endif
+// The entry is ONE frame of 64 KiB blocks, nothing optional but a content size that agrees with the entry, nothing behind its EndMark:
+// its block table (offsets relative to the entry).  Anything else: false (the one-wave decoder's).
+static bool walk_lz4_single(const u8* p, u64 comp, u64 uncomp, std::vector<PjBlock>& blocks, int& independent)
+{
+    blocks.clear();
+    if (comp < 7 + 4 || comp >= 0x7FFF0000ull || uncomp >= 0x7FFF0000ull || hrd32(p) != 0x184D2204u) return false;
+    const u8 flg = p[4], bd = p[5];
+    if ((flg >> 6) != 1 || (flg & 0x03) || (flg & 0x10) || (flg & 0x04) || bd != 0x40) return false;      // version 01, no dictionary, no block / content checksums, 64 KiB blocks
+    const u32 hdr = 7 + ((flg & 0x08) ? 8u : 0u);
+    if (comp < hdr + 4) return false;
+    if ((flg & 0x08) && hrd64(p + 6) != uncomp) return false;
+    if (((host_xxh32_small(p + 4, hdr - 5) >> 8) & 0xFF) != p[hdr - 1]) return false;
+    independent = (flg >> 5) & 1;
+    u64 q = hdr, recs = 0;
+    for (;;) {
+        if (comp - q < 4) return false;
+        const u32 w = hrd32(p + q); q += 4;
+        if (w == 0) break;
+        const u32 n = w & 0x7FFFFFFFu;
+        if (n == 0 || n > PJ_BLOCK || n > comp - q) return false;
+        PjBlock B; B.comp_off = (u32)q; B.comp_size = w; B.rec_base = (u32)recs; B.out_size = 0; B.out_off = 0; B.nrec = 0;
+        if (!(w >> 31)) recs += n / 3 + 2;
+        if (recs > 0xFFFFFF00ull) return false;
+        blocks.push_back(B);
+        q += n;
+    }
+    return q == comp && blocks.size() >= ZPK_PJ_MIN_BLOCKS;
+}
+
+// -> ZPK_OK with redo = 0: the entry is decoded, hashed and delivered; redo = 1: not this path's (the one-wave decoder decides)
+static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_decode_desc& d, const std::vector<PjBlock>& blocks, int independent,
+                                 uint8_t* dst_ptr, zpk_decode_result& result, u8& redo)
+{
+    redo = 1;
+    const u64 nb = blocks.size(), n = d.uncomp_size;
+    const u64 total_recs = (u64)blocks.back().rec_base + ((blocks.back().comp_size >> 31) ? 0 : (blocks.back().comp_size / 3 + 2));
+    int rc;
+    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, d.comp_size + ZPK_SRC_SLACK)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, n + 16)) ||
+        (rc = grow(c, &c->d_pj_blocks, &c->pj_blocks_cap, nb * sizeof(PjBlock))) || (rc = grow(c, &c->d_pj_recs, &c->pj_recs_cap, (total_recs + 64) * 8)) ||
+        (rc = grow(c, &c->d_pj_masks, &c->pj_masks_cap, nb * (PJ_BLOCK / 8))) || (rc = grow(c, &c->d_pj_S, &c->pj_S_cap, n * 4 + 64))) { c->err[0] = 0; return ZPK_OK; }     // no memory for the scratch: the one-wave decoder
+    if (!c->d_pj_flags && hipMalloc((void**)&c->d_pj_flags, 64) != hipSuccess) { c->d_pj_flags = nullptr; (void)hipGetLastError(); return ZPK_OK; }
+    hipStream_t st = c->stream;
+    hipError_t e = hipMemcpyAsync(c->d_src, archive + d.src_offset, d.comp_size, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_pj_blocks, blocks.data(), nb * sizeof(PjBlock), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_pj_flags, 0, 64, st);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    PjBlock* const B = (PjBlock*)c->d_pj_blocks;
+    u32* const S = (u32*)c->d_pj_S;
+    hipLaunchKernelGGL(k_pj_parse, dim3((u32)nb), dim3(64), 0, st, (const u8*)c->d_src, d.comp_size, B, (u32)nb, (u64*)c->d_pj_recs, (u32*)c->d_pj_masks, c->d_pj_flags);
+    hipLaunchKernelGGL(k_pj_scan, dim3(1), dim3(64), 0, st, B, (u32)nb, c->d_pj_flags);
+    u32 hf[4] = {0, 0, 0, 0};
+    e = hipMemcpyAsync(hf, c->d_pj_flags, sizeof(hf), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    if (hf[PJ_ERR] || (((u64)hf[PJ_TOTAL + 1] << 32) | hf[PJ_TOTAL]) != n) return ZPK_OK;          // irregular, or the sizes do not add up
+    hipLaunchKernelGGL(k_pj_init, dim3((u32)nb), dim3(256), 0, st, (const PjBlock*)B, (u32)nb, (const u64*)c->d_pj_recs, (const u32*)c->d_pj_masks, S, c->d_pj_flags, independent);
+    const u32 jgrid = (u32)((n + 1023) / 1024);
+    int rounds = 0;
+    for (;; rounds++) {
+        if (rounds > 40) return ZPK_OK;                                                             // (cannot happen: a chain halves per round)
+        (void)hipMemsetAsync(c->d_pj_flags + PJ_CHANGED, 0, 4, st);
+        hipLaunchKernelGGL(k_pj_jump, dim3(jgrid), dim3(256), 0, st, S, n, c->d_pj_flags);
+        e = hipMemcpyAsync(hf, c->d_pj_flags, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+        if (hf[PJ_ERR]) return ZPK_OK;
+        if (!hf[PJ_CHANGED]) break;
+    }
+    hipLaunchKernelGGL(k_pj_gather, dim3(jgrid), dim3(256), 0, st, (const u32*)S, n, (const u8*)c->d_src, d.comp_size, c->d_dst, c->d_pj_flags);
+    zpk_span span; span.off = 0; span.len = n; span.part_base = 0;
+    u64 h = 0;
+    if ((rc = xxh3_spans_launch(c, c->d_dst, &span, 1, xxh3_span_blocks(n), &h, st))) return rc;
+    e = hipMemcpyAsync(hf, c->d_pj_flags, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    if (hf[PJ_ERR]) return ZPK_OK;
+    uint8_t* optr[1] = { dst_ptr };
+    rc = d2h_scatter(c, c->d_dst, n, 1, optr, [&](u64) { return (u64)0; }, [&](u64) { return n; }, e);
+    if (rc) return rc;
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "D2H: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    result.hash = h; result.produced = n; result.detail = 0;
+    result.status = ((d.flags & ZPK_DF_SKIP_HASH) || h == d.expect_hash) ? 0 : 15;                  // ZPACK_ERROR_FILE_HASH_MISMATCH, lib/zpack_read.c:467
+    c->big_last[0]++; c->big_last[1] += (u32)nb; c->pj_last_rounds = (u32)rounds + 1;
+    redo = 0;
+    return ZPK_OK;
+}
+
 // the frames of entries [g0, g1) of `be` as one device batch; redo[k] = 1: entry k takes the serial path after all
 static int decode_big_group(zpk_codec* c, const u8* archive, const zpk_decode_desc* desc, const BigEntry* be, u64 g0, u64 g1,
                             const std::vector<BigSub>& subs, uint8_t* const* dst_ptrs, zpk_decode_result* results, u8* redo)
@@ -1448,6 +1559,8 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
     // ---- which entries are sequences of frames worth decoding frame-parallel ----
     std::vector<BigEntry> be;
     std::vector<BigSub> subs;
+    struct PjEntry { u64 idx; std::vector<PjBlock> blocks; int independent; };
+    std::vector<PjEntry> pj;                                                          // large single LZ4 frames (lz4_pj.h)
     if (archive && c->dec_split_min != ~0ull) {
         try {
             for (u64 i = 0; i < n; i++) {
@@ -1465,13 +1578,19 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
                         }
                         ok = true;
                     }
-                } else if (d.method == ZPK_METHOD_LZ4) ok = walk_lz4_frames(archive + d.src_offset, d.comp_size, d.uncomp_size, subs);
+                } else if (d.method == ZPK_METHOD_LZ4) {
+                    ok = walk_lz4_frames(archive + d.src_offset, d.comp_size, d.uncomp_size, subs);
+                    if (!ok) {                                                        // ONE frame (what the reference writes): block-parallel
+                        PjEntry P; P.idx = i; P.independent = 0;
+                        if (walk_lz4_single(archive + d.src_offset, d.comp_size, d.uncomp_size, P.blocks, P.independent)) pj.push_back(std::move(P));
+                    }
+                }
                 else ok = walk_zstd_frames(archive + d.src_offset, d.comp_size, d.uncomp_size, subs);
                 if (ok) be.push_back(BigEntry{ i, (u64)s0, (u64)(subs.size() - s0) });
             }
-        } catch (...) { be.clear(); subs.clear(); }                                   // out of host memory for the plan: the usual path
+        } catch (...) { be.clear(); subs.clear(); pj.clear(); }                       // out of host memory for the plan: the usual path
     }
-    if (be.empty()) {
+    if (be.empty() && pj.empty()) {
         const int rc = decode_batch_host_plain(c, archive, archive_size, desc, n, dst_ptrs, results);
         c->zstd_hint = -1; c->lz4_hint = -1;
         return rc;
@@ -1487,6 +1606,11 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
         }
         // ---- everything else, and the entries a frame of which did not decode, through the usual path ----
         for (u64 k = 0; k < be.size(); k++) if (!redo[k]) is_big[be[k].idx] = 1;
+        for (u64 k = 0; k < pj.size() && rc == ZPK_OK; k++) {                         // one large frame at a time: each fills the chip
+            u8 again = 1;
+            rc = decode_big_lz4_single(c, archive, desc[pj[k].idx], pj[k].blocks, pj[k].independent, dst_ptrs[pj[k].idx], results[pj[k].idx], again);
+            if (rc == ZPK_OK && !again) is_big[pj[k].idx] = 1;
+        }
         std::vector<u64> rest;
         for (u64 i = 0; i < n; i++) if (!is_big[i]) rest.push_back(i);
         if (rc == ZPK_OK && !rest.empty()) {
