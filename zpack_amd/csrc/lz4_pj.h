@@ -99,16 +99,17 @@ __global__ __launch_bounds__(64) void k_pj_scan(PjBlock* __restrict__ blocks, u3
     if (lane == 0) { flags[PJ_TOTAL] = (u32)base; flags[PJ_TOTAL + 1] = (u32)(base >> 32); }
 }
 
-// one workgroup of 256 threads per block: references of its output bytes
-__global__ __launch_bounds__(256) void k_pj_init(const PjBlock* __restrict__ blocks, u32 nblocks, const u64* __restrict__ recs,
-                                                 const u32* __restrict__ masks, u32* __restrict__ S, u32* __restrict__ flags, int independent)
+// one workgroup of 256 threads per block (blocks b0 + blockIdx.x): references of its output bytes.  n = bytes of S (nothing beyond is touched)
+__global__ __launch_bounds__(256) void k_pj_init(const PjBlock* __restrict__ blocks, u32 b0, u32 nblocks, const u64* __restrict__ recs,
+                                                 const u32* __restrict__ masks, u32* __restrict__ S, u64 n, u32* __restrict__ flags, int independent)
 {
     __shared__ u32 m[PJ_BLOCK / 32];
     __shared__ u32 pre[PJ_BLOCK / 32];             // set bits in front of word w
     __shared__ u32 part[256];
-    const u32 b = blockIdx.x, tid = threadIdx.x;
+    const u32 b = b0 + blockIdx.x, tid = threadIdx.x;
     if (b >= nblocks) return;
     const PjBlock B = blocks[b];
+    if ((u64)B.out_off + B.out_size > n) { if (tid == 0) atomicOr(&flags[PJ_ERR], 16u); return; }
     u32* const out = S + B.out_off;
     if (B.comp_size >> 31) {
         for (u32 i = tid; i < B.out_size; i += 256) out[i] = PJ_LIT | (B.comp_off + i);
@@ -119,8 +120,7 @@ __global__ __launch_bounds__(256) void k_pj_init(const PjBlock* __restrict__ blo
     for (u32 k = 0; k < 8; k++) { const u32 w = tid * 8 + k; const u32 v = gm[w]; m[w] = v; pre[w] = cnt; cnt += (u32)__popc(v); }
     part[tid] = cnt;
     __syncthreads();
-    // exclusive scan of the 256 partial counts (small: every thread sums what lies before it, wave by wave)
-    u32 before = 0;
+    u32 before = 0;                                // (256 partial counts: every thread sums what lies before it)
     for (u32 t = 0; t < tid; t++) before += part[t];
     __syncthreads();
     for (u32 k = 0; k < 8; k++) pre[tid * 8 + k] += before;
@@ -144,39 +144,63 @@ __global__ __launch_bounds__(256) void k_pj_init(const PjBlock* __restrict__ blo
     if (bad) atomicOr(&flags[PJ_ERR], 4u);
 }
 
-// S[i] = S[S[i]] for the bytes that still refer to an output byte (in place: a value read early or late is a valid reference either way)
-__global__ __launch_bounds__(256) void k_pj_jump(u32* __restrict__ S, u64 n, u32* __restrict__ flags)
+// The frame is resolved in CHUNKS of consecutive blocks [b0, b1) — a chunk's references (4 bytes per output byte) should stay in the
+// Infinity Cache — one after the other: a reference to a byte in front of the chunk is FINAL (that byte is in the output already).
+#define PJ_ROUND0 8                              // flags[PJ_ROUND0 + r]: round r of the current chunk left a byte unresolved
+#define PJ_MAX_ROUNDS 28
+__device__ __forceinline__ void pj_range(const PjBlock* blocks, u32 b0, u32 b1, u32 nblocks, const u32* flags, u32& lo, u32& hi)
 {
-    const u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
+    lo = blocks[b0].out_off;
+    hi = b1 < nblocks ? blocks[b1].out_off : flags[PJ_TOTAL];
+}
+// round r: S[i] = S[S[i]] for the chunk's bytes that still refer to a byte of the chunk (in place: a value read early or late is a valid
+// reference either way).  Launched PJ_MAX_ROUNDS times per chunk without a host round trip: a round behind the last one that changed
+// anything returns at once.
+__global__ __launch_bounds__(256) void k_pj_jump(u32* __restrict__ S, const PjBlock* __restrict__ blocks, u32 b0, u32 b1, u32 nblocks,
+                                                 u32* __restrict__ flags, u32 r)
+{
+    if (r > 0 && flags[PJ_ROUND0 + r - 1] == 0) return;
+    u32 lo, hi;
+    pj_range(blocks, b0, b1, nblocks, flags, lo, hi);
+    // a workgroup owns 1024 consecutive references; thread t those at t, t + 256, t + 512, t + 768: every load of a wave is 256 contiguous
+    // bytes, and the references it then follows are consecutive wherever the bytes belong to one match
+    const u64 base = (u64)lo + (u64)blockIdx.x * 1024 + threadIdx.x;
+    u32 v[4]; bool mine[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const u64 i = base + 256u * k; v[k] = i < hi ? S[i] : PJ_LIT; mine[k] = !(v[k] >> 31) && v[k] >= lo; }
+    u32 w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = mine[k] ? S[v[k]] : v[k];
     bool open = false;
-    if (i + 4 <= n) {
-        v4u32 v = *(const ZPK_GLOBAL v4u32*)(S + i);
-        bool ch = false;
-        if (!(v.x >> 31)) { v.x = S[v.x]; ch = true; open |= !(v.x >> 31); }
-        if (!(v.y >> 31)) { v.y = S[v.y]; ch = true; open |= !(v.y >> 31); }
-        if (!(v.z >> 31)) { v.z = S[v.z]; ch = true; open |= !(v.z >> 31); }
-        if (!(v.w >> 31)) { v.w = S[v.w]; ch = true; open |= !(v.w >> 31); }
-        if (ch) *(ZPK_GLOBAL v4u32*)(S + i) = v;
-    } else {
-        for (u64 k = i; k < n; k++) { u32 v = S[k]; if (!(v >> 31)) { v = S[v]; S[k] = v; open |= !(v >> 31); } }
-    }
-    if (__ballot(open) != 0 && lane_id() == 0) atomicOr(&flags[PJ_CHANGED], 1u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (mine[k]) { S[base + 256u * k] = w[k]; open |= !(w[k] >> 31) && w[k] >= lo; }
+    // one word says "this round left something open": thousands of atomics on it would take longer than the round (12 ns each), so a
+    // wave looks first and only the first few write
+    if (__ballot(open) != 0 && lane_id() == 0 && __hip_atomic_load(&flags[PJ_ROUND0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __hip_atomic_store(&flags[PJ_ROUND0 + r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// every reference is a literal now: out[i] = src[S[i]]
-__global__ __launch_bounds__(256) void k_pj_gather(const u32* __restrict__ S, u64 n, const u8* __restrict__ src, u64 src_size, u8* __restrict__ dst,
-                                                   u32* __restrict__ flags)
+// the chunk's bytes: a literal of the compressed entry, or a byte of the output in front of the chunk
+__global__ __launch_bounds__(256) void k_pj_gather(const u32* __restrict__ S, const PjBlock* __restrict__ blocks, u32 b0, u32 b1, u32 nblocks,
+                                                   const u8* __restrict__ src, u64 src_size, u8* __restrict__ dst, u32* __restrict__ flags)
 {
-    const u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
+    u32 lo, hi;
+    pj_range(blocks, b0, b1, nblocks, flags, lo, hi);
+    const u64 i = (u64)(lo & ~3u) + ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= hi) return;
     bool bad = false;
-    if (i + 4 <= n) {
-        const v4u32 v = *(const ZPK_GLOBAL v4u32*)(S + i);
-        const u32 a0 = v.x & 0x7FFFFFFFu, a1 = v.y & 0x7FFFFFFFu, a2 = v.z & 0x7FFFFFFFu, a3 = v.w & 0x7FFFFFFFu;
-        bad = !((v.x & v.y & v.z & v.w) >> 31) || a0 >= src_size || a1 >= src_size || a2 >= src_size || a3 >= src_size;
-        if (!bad) *(ZPK_GLOBAL u32*)(dst + i) = (u32)ld8(src + a0) | ((u32)ld8(src + a1) << 8) | ((u32)ld8(src + a2) << 16) | ((u32)ld8(src + a3) << 24);
-    } else {
-        for (u64 k = i; k < n; k++) { const u32 v = S[k]; const u32 a = v & 0x7FFFFFFFu; if (!(v >> 31) || a >= src_size) bad = true; else dst[k] = ld8(src + a); }
+    u32 word = 0;
+    const u64 k0 = i < lo ? lo : i, k1 = i + 4 < hi ? i + 4 : hi;
+    for (u64 k = k0; k < k1; k++) {
+        const u32 v = S[k];
+        u32 byte = 0;
+        if (v >> 31) { const u32 a = v & 0x7FFFFFFFu; if (a >= src_size) bad = true; else byte = ld8(src + a); }
+        else if (v < lo) byte = ld8(dst + v);
+        else bad = true;                                         // (not resolved: cannot happen after PJ_MAX_ROUNDS)
+        word |= byte << (8 * (u32)(k - i));
     }
+    if (k0 == i && k1 == i + 4) *(ZPK_GLOBAL u32*)(dst + i) = word;
+    else for (u64 k = k0; k < k1; k++) dst[k] = (u8)(word >> (8 * (u32)(k - i)));
     if (bad) atomicOr(&flags[PJ_ERR], 8u);
 }
 

@@ -18,11 +18,12 @@ __device__ __forceinline__ u64 shfl64(u64 v, int from)
 }
 struct zpk_span { u64 off, len, part_base; };    // part_base: index of the span's first block among the partial sums (a multiple of 64)
 #define XS_GROUP 64u                             // blocks per wave of the partial pass
+// groups [g_first, ngroups) of 64 blocks (a caller whose span becomes final piece by piece launches a range of groups per piece)
 __global__ __launch_bounds__(256) void k_xxh3_partials(const u8* __restrict__ src, const zpk_span* __restrict__ spans, u32 nspans,
-                                                       u64 ngroups, u64* __restrict__ partial)
+                                                       u64 g_first, u64 ngroups, u64* __restrict__ partial)
 {
     const int lane = lane_id();
-    const u64 g = uni64((u64)blockIdx.x * 4 + (threadIdx.x >> 6));
+    const u64 g = uni64(g_first + (u64)blockIdx.x * 4 + (threadIdx.x >> 6));
     if (g >= ngroups) return;
     u32 lo = 0, hi = nspans;                                                          // last span with part_base / 64 <= g
     while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (spans[mid].part_base / XS_GROUP <= g) lo = mid; else hi = mid; }
@@ -47,29 +48,48 @@ __global__ __launch_bounds__(256) void k_xxh3_partials(const u8* __restrict__ sr
         }
     }
 }
+// One wave per span.  The chain may be run in SECTIONS (a span that becomes final piece by piece): blocks [b_from, b_to) of the span,
+// the eight accumulators carried in state[8 * span ..] between the launches; the launch with last != 0 finishes the span (every block
+// still open, the tail, the avalanche).  state == nullptr: the whole span at once.
 __global__ __launch_bounds__(64) void k_xxh3_chain(const u8* __restrict__ src, const zpk_span* __restrict__ spans, const u64* __restrict__ partial,
-                                                   u64* __restrict__ hash_out)
+                                                   u64* __restrict__ hash_out, u64* __restrict__ state, u64 b_from, u64 b_to, int last)
 {
     const int lane = lane_id(), q = lane & 3, j = lane >> 2;
     const zpk_span sp = spans[blockIdx.x];
     const u8* p = uni_ptr(src + sp.off);
     const u64 len = uni64(sp.len), nblocks = (len - 1) >> 10;
+    const u64 bend = (state == nullptr || last || b_to > nblocks) ? nblocks : b_to;
     Xxh3Wave w; w.init(lane);
-    const u64* part = partial + sp.part_base * 8 + 2 * q;
-    // sixteen blocks' sums per load (lane group j holds block b + j), the next sixteen in flight meanwhile
-    #define XS_LD(b) ((b) + (u64)j < nblocks ? ld128((const u8*)(part + ((b) + (u64)j) * 8)) : u128{0, 0})
-    u128 cur = XS_LD(0);
-    for (u64 b = 0; b < nblocks; b += 16) {
-        const u128 nxt = XS_LD(b + 16);
-        const u32 m = (u32)(nblocks - b < 16 ? nblocks - b : 16);
-        for (u32 k = 0; k < m; k++) {
-            const int from = (int)(4 * k) + q;
-            w.a0 += shfl64(cur.lo, from); w.a1 += shfl64(cur.hi, from);
-            w.scramble();
-        }
-        cur = nxt;
+    // (round 5) The chain is ONE wave's instruction stream, so what it costs is instructions per block.  Lane l carries accumulator
+    // l & 7 alone (Xxh3Wave's pair per lane would be twice the instructions) and reads its sum itself — the eight lanes of a group read
+    // one 64-byte line per block, sixteen blocks per trip, the next sixteen in flight meanwhile: no cross-lane traffic.  Before, a
+    // block's sums came through four ds_bpermute in front of two scrambles per lane: ~330 cycles per block, 36 ms for the 262 144
+    // blocks of a 256 MiB span — as long as the block-parallel decode of the entry in front of it.
+    (void)q; (void)j;
+    const int ai = lane & 7;
+    const u64 init[8] = { ZPK_P32_3, ZPK_P64_1, ZPK_P64_2, ZPK_P64_3, ZPK_P64_4, ZPK_P32_2, ZPK_P64_5, ZPK_P32_1 };
+    u64 acc = init[0];
+    #pragma unroll
+    for (int t = 1; t < 8; t++) acc = ai == t ? init[t] : acc;
+    u64 b = 0;
+    if (state != nullptr && b_from != 0) { acc = state[8 * (u64)blockIdx.x + ai]; b = uni64(b_from); }
+    const u64 sk = sec64(128 + 8 * ai);
+    const u64* const part = partial + sp.part_base * 8 + ai;
+    constexpr u32 NB = 16;
+    u64 cur[NB], nxt[NB];
+    #pragma unroll
+    for (u32 t = 0; t < NB; t++) cur[t] = b + t < bend ? part[(b + t) * 8] : 0ull;
+    for (; b + NB <= bend; b += NB) {
+        #pragma unroll
+        for (u32 t = 0; t < NB; t++) nxt[t] = b + NB + t < bend ? part[(b + NB + t) * 8] : 0ull;
+        #pragma unroll
+        for (u32 t = 0; t < NB; t++) { acc += cur[t]; acc = ((acc ^ (acc >> 47)) ^ sk) * ZPK_P32_1; }
+        #pragma unroll
+        for (u32 t = 0; t < NB; t++) cur[t] = nxt[t];
     }
-    #undef XS_LD
+    for (; b < bend; b++) { acc += part[b * 8]; acc = ((acc ^ (acc >> 47)) ^ sk) * ZPK_P32_1; }      // (fewer than sixteen left)
+    if (state != nullptr && !last) { if (lane < 8) state[8 * (u64)blockIdx.x + lane] = acc; return; }
+    w.a0 = shfl64(acc, 2 * q); w.a1 = shfl64(acc, 2 * q + 1);                         // back to the pair per lane the tail works on
     const u32 nstripes = (u32)(((len - 1) - (nblocks << 10)) >> 6);
     const u64 h = uni64(w.finish(p + (nblocks << 10), nstripes, p + len, len, lane));
     lane0_guard();
