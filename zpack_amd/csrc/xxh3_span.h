@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_xxh3_partials(const u8* __restrict__ sr
     const u32 nb = (u32)(nblocks - b0 < XS_GROUP ? nblocks - b0 : XS_GROUP);
     Xxh3Wave w; w.init(lane);
     const u8* q = src + sp.off + (b0 << 10) + 16 * lane;
-    u64* out = partial + (sp.part_base + b0) * 8 + 2 * (lane & 3);
+    u64* out = partial + (sp.part_base + b0) * 8 + 128 * (lane & 3);                  // a group's sums lie [accumulator][block]: the chain's lane reads ITS 64 sums as 512 contiguous bytes
     for (u32 j = 0; j < nb; j += 4) {                                                 // four blocks' loads in flight (unconditional: past the end the last block again)
         u128 d[4];
         #pragma unroll
@@ -44,9 +44,18 @@ __global__ __launch_bounds__(256) void k_xxh3_partials(const u8* __restrict__ sr
             u64 c0, c1;
             Xxh3Wave::slot(d[t].lo, d[t].hi, w.k0, w.k1, c0, c1);
             Xxh3Wave::reduce16<true>(c0, c1);
-            if (lane < 4 && j + t < nb) { out[(u64)(j + t) * 8] = c0; out[(u64)(j + t) * 8 + 1] = c1; }
+            if (lane < 4 && j + t < nb) { out[j + t] = c0; out[64 + j + t] = c1; }
         }
     }
+}
+// One step of the chain: (lo, hi) = the accumulator with its block's sum already added; scrambled, and the NEXT block's sum added (the
+// compiler folds that addition into the multiply-add).  Three formulations of this step — 7 to 9 instructions, one or two dependent
+// multiplies — differ by 7 % (profiles/r05/r05_xxh3_chain_variants.txt): this is the shortest.
+__device__ __forceinline__ void chain_step(u32& lo, u32& hi, u64 sum_next, u64 key)
+{
+    u64 acc = ((u64)hi << 32) | lo;
+    acc = ((acc ^ (acc >> 47)) ^ key) * ZPK_P32_1 + sum_next;
+    lo = (u32)acc; hi = (u32)(acc >> 32);
 }
 // One wave per span.  The chain may be run in SECTIONS (a span that becomes final piece by piece): blocks [b_from, b_to) of the span,
 // the eight accumulators carried in state[8 * span ..] between the launches; the launch with last != 0 finishes the span (every block
@@ -74,20 +83,45 @@ __global__ __launch_bounds__(64) void k_xxh3_chain(const u8* __restrict__ src, c
     u64 b = 0;
     if (state != nullptr && b_from != 0) { acc = state[8 * (u64)blockIdx.x + ai]; b = uni64(b_from); }
     const u64 sk = sec64(128 + 8 * ai);
-    const u64* const part = partial + sp.part_base * 8 + ai;
-    constexpr u32 NB = 16;
-    u64 cur[NB], nxt[NB];
-    #pragma unroll
-    for (u32 t = 0; t < NB; t++) cur[t] = b + t < bend ? part[(b + t) * 8] : 0ull;
-    for (; b + NB <= bend; b += NB) {
+    // The sums of a group of 64 blocks lie [accumulator][block] (k_xxh3_partials): a lane's 64 sums are 32 loads of 16 bytes, all in
+    // flight while the group before is chained.  (With 16 sums of 8 bytes per trip the wave waited ~0.9 us of load latency per trip:
+    // 59 ns per block whatever the arithmetic; now 46 ns, 12.1 ms per 256 MiB.)
+    const u8* const part = (const u8*)(partial + sp.part_base * 8 + 64 * ai);          // + 4096 bytes per group
+    constexpr u32 NL = XS_GROUP / 2;
+    u128 cur[NL], nxt[NL];
+    const u64 g_end = (bend + XS_GROUP - 1) / XS_GROUP;                                 // groups [b / 64, g_end); the last may be short
+    u64 g = b / XS_GROUP;
+    if (g < g_end) {
         #pragma unroll
-        for (u32 t = 0; t < NB; t++) nxt[t] = b + NB + t < bend ? part[(b + NB + t) * 8] : 0ull;
+        for (u32 t = 0; t < NL; t++) cur[t] = ld128(part + g * 4096 + 16 * t);
+    } else {
         #pragma unroll
-        for (u32 t = 0; t < NB; t++) { acc += cur[t]; acc = ((acc ^ (acc >> 47)) ^ sk) * ZPK_P32_1; }
-        #pragma unroll
-        for (u32 t = 0; t < NB; t++) cur[t] = nxt[t];
+        for (u32 t = 0; t < NL; t++) cur[t] = u128{0, 0};
     }
-    for (; b < bend; b++) { acc += part[b * 8]; acc = ((acc ^ (acc >> 47)) ^ sk) * ZPK_P32_1; }      // (fewer than sixteen left)
+    acc += b < bend ? cur[0].lo : 0ull;                                                 // (a step adds the sum of the block BEHIND its own)
+    u32 lo = (u32)acc, hi = (u32)(acc >> 32);
+    for (; g < g_end; g++) {
+        const bool more = g + 1 < g_end;
+        #pragma unroll
+        for (u32 t = 0; t < NL; t++) nxt[t] = more ? ld128(part + (g + 1) * 4096 + 16 * t) : u128{0, 0};
+        const u64 left = bend - g * XS_GROUP;                                           // blocks of this group that exist (>= 1)
+        if (left >= XS_GROUP) {
+            #pragma unroll
+            for (u32 t = 0; t < NL; t++) {
+                chain_step(lo, hi, cur[t].hi, sk);
+                chain_step(lo, hi, t + 1 < NL ? cur[t + 1].lo : (left > XS_GROUP ? nxt[0].lo : 0ull), sk);
+            }
+        } else {
+            #pragma unroll
+            for (u32 t = 0; t < NL; t++) {
+                if (2 * t < left) chain_step(lo, hi, 2 * t + 1 < left ? cur[t].hi : 0ull, sk);
+                if (2 * t + 1 < left) chain_step(lo, hi, (t + 1 < NL && 2 * t + 2 < left) ? cur[t + 1].lo : 0ull, sk);
+            }
+        }
+        #pragma unroll
+        for (u32 t = 0; t < NL; t++) cur[t] = nxt[t];
+    }
+    acc = ((u64)hi << 32) | lo;
     if (state != nullptr && !last) { if (lane < 8) state[8 * (u64)blockIdx.x + lane] = acc; return; }
     w.a0 = shfl64(acc, 2 * q); w.a1 = shfl64(acc, 2 * q + 1);                         // back to the pair per lane the tail works on
     const u32 nstripes = (u32)(((len - 1) - (nblocks << 10)) >> 6);

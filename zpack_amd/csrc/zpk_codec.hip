@@ -1508,14 +1508,40 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
     zpk_span span; span.off = 0; span.len = n; span.part_base = 0;
     e = hipMemcpyAsync(d_span, &span, sizeof(span), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    // ---- the output to the caller's buffer starts while the chunks are still being resolved: d2h_scatter (pinned staging, the copy of piece
+    // j + 1 on the bus while piece j is copied out by a few threads) runs on a helper thread and takes a piece as soon as the chunks under it
+    // have been ENQUEUED (their events recorded).  The bytes are the entry's whatever the verdict (lib/zpack_read.c:466-468 leaves
+    // them); if the path turns out not to have been regular the one-wave decoder overwrites them. ----
+    std::vector<u64> chunk_hi(nchunks);
+    for (u64 k = 0; k < nchunks; k++) { const u64 b1 = (k + 1) * ZPK_PJ_CHUNK_BLOCKS; chunk_hi[k] = b1 < nb ? hb[b1].out_off : n; }
+    std::atomic<u64> enqueued{0};
+    std::atomic<int> give_up{0};
+    int dn_rc = ZPK_OK; hipError_t dn_e = hipSuccess;
+    auto download = [&]() {
+        (void)hipSetDevice(c->device);
+        u64 waited = 0;
+        auto pre = [&](u64 q1) -> hipError_t {
+            while (waited < nchunks && (waited == 0 || chunk_hi[waited - 1] < q1)) {
+                while (enqueued.load(std::memory_order_acquire) <= waited) { if (give_up.load(std::memory_order_acquire)) return hipErrorUnknown; std::this_thread::yield(); }
+                const hipError_t we = hipStreamWaitEvent(c->s_dn, c->pj_ev[waited], 0);
+                if (we != hipSuccess) return we;
+                waited++;
+            }
+            return hipSuccess;
+        };
+        uint8_t* optr[1] = { dst_ptr };
+        dn_rc = d2h_scatter(c, c->d_dst, n, 1, optr, [&](u64) { return (u64)0; }, [&](u64) { return n; }, dn_e, c->s_dn, pre);
+    };
+    std::thread dn_thread;
+    bool dn_started = false;
+    try { dn_thread = std::thread(download); dn_started = true; } catch (...) { dn_started = false; }      // (no thread: the download follows the loop)
     // ---- every chunk: references, PJ_MAX_ROUNDS rounds of pointer doubling (a round behind the last one that changed anything returns at
     // once: no host round trip), the gather; an event behind each chunk lets its bytes be hashed and go home while the next is resolved ----
-    std::vector<u64> chunk_hi(nchunks);
+    bool launch_failed = false;
     u64 g_lo = 0;
     for (u64 k = 0; k < nchunks; k++) {
         const u32 b0 = (u32)(k * ZPK_PJ_CHUNK_BLOCKS), b1 = (u32)(b0 + ZPK_PJ_CHUNK_BLOCKS < nb ? b0 + ZPK_PJ_CHUNK_BLOCKS : nb);
-        const u64 lo = hb[b0].out_off, hi = b1 < nb ? hb[b1].out_off : n;
-        chunk_hi[k] = hi;
+        const u64 lo = hb[b0].out_off, hi = chunk_hi[k];
         const u32 grid = (u32)((hi - (lo & ~3ull) + 1023) / 1024), jgrid = (u32)((hi - lo + 1023) / 1024);
         (void)hipMemsetAsync(c->d_pj_flags + PJ_ROUND0, 0, PJ_MAX_ROUNDS * 4, st);
         hipLaunchKernelGGL(k_pj_init, dim3(b1 - b0), dim3(256), 0, st, (const PjBlock*)B, b0, (u32)nb, (const u64*)c->d_pj_recs, (const u32*)c->d_pj_masks, S, n, c->d_pj_flags, independent);
@@ -1524,7 +1550,8 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
                 hipLaunchKernelGGL(k_pj_jump, dim3(jgrid), dim3(256), 0, st, S, (const PjBlock*)B, b0, b1, (u32)nb, c->d_pj_flags, r);
             hipLaunchKernelGGL(k_pj_gather, dim3(grid), dim3(256), 0, st, (const u32*)S, (const PjBlock*)B, b0, b1, (u32)nb, (const u8*)c->d_src, d.comp_size, c->d_dst, c->d_pj_flags);
         }
-        if (hipEventRecord(c->pj_ev[k], st) != hipSuccess || hipStreamWaitEvent(sh, c->pj_ev[k], 0) != hipSuccess) { (void)hipDeviceSynchronize(); return ZPK_E_LAUNCH; }
+        if (hipEventRecord(c->pj_ev[k], st) != hipSuccess || hipStreamWaitEvent(sh, c->pj_ev[k], 0) != hipSuccess) { launch_failed = true; break; }
+        enqueued.store(k + 1, std::memory_order_release);
         const bool last = k + 1 == nchunks;
         const u64 g_hi = last ? ngroups : (hi >> 10) / XS_GROUP;                       // groups of 64 blocks that are final now
         if (g_hi > g_lo) hipLaunchKernelGGL(k_xxh3_partials, dim3((u32)((g_hi - g_lo + 3) / 4)), dim3(256), 0, sh, (const u8*)c->d_dst, (const zpk_span*)d_span, 1u, g_lo, g_hi, d_part);
@@ -1532,25 +1559,17 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
             hipLaunchKernelGGL(k_xxh3_chain, dim3(1), dim3(64), 0, sh, (const u8*)c->d_dst, (const zpk_span*)d_span, (const u64*)d_part, d_hash, d_state, g_lo * XS_GROUP, g_hi * XS_GROUP, last ? 1 : 0);
         if (g_hi > g_lo) g_lo = g_hi;
     }
-    e = hipMemcpyAsync(&c->h_pj[0], d_hash, 8, hipMemcpyDeviceToHost, sh);
+    if (launch_failed) give_up.store(1, std::memory_order_release);
+    e = launch_failed ? hipErrorUnknown : hipMemcpyAsync(&c->h_pj[0], d_hash, 8, hipMemcpyDeviceToHost, sh);
     if (e == hipSuccess) e = hipMemcpyAsync(&c->h_pj[1], c->d_pj_flags, 4, hipMemcpyDeviceToHost, sh);
-    if (e != hipSuccess) { (void)hipDeviceSynchronize(); snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
-    // ---- the output to the caller's buffer, chunk by chunk as it becomes final (d2h_scatter: pinned staging, the copy of piece j + 1 on
-    // the bus while piece j is copied out).  The bytes are the entry's whatever the verdict (lib/zpack_read.c:466-468 leaves them); if the
-    // path turns out not to have been regular the one-wave decoder overwrites them. ----
-    u64 waited = 0;
-    auto pre = [&](u64 q1) -> hipError_t {
-        while (waited < nchunks && (waited == 0 || chunk_hi[waited - 1] < q1)) {
-            const hipError_t we = hipStreamWaitEvent(c->s_dn, c->pj_ev[waited], 0);
-            if (we != hipSuccess) return we;
-            waited++;
-        }
-        return hipSuccess;
-    };
-    uint8_t* optr[1] = { dst_ptr };
-    rc = d2h_scatter(c, c->d_dst, n, 1, optr, [&](u64) { return (u64)0; }, [&](u64) { return n; }, e, c->s_dn, pre);
-    if (rc) { (void)hipDeviceSynchronize(); return rc; }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->s_dn);
+    if (dn_started) dn_thread.join(); else if (!launch_failed) download();
+    if (e != hipSuccess || dn_rc != ZPK_OK || dn_e != hipSuccess) {
+        (void)hipDeviceSynchronize();
+        if (dn_rc != ZPK_OK && !launch_failed) return dn_rc;
+        snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e != hipSuccess ? e : dn_e));
+        return ZPK_E_LAUNCH;
+    }
+    e = hipStreamSynchronize(c->s_dn);
     const hipError_t e2 = hipStreamSynchronize(sh), e3 = hipStreamSynchronize(st);
     if (e == hipSuccess) e = e2 != hipSuccess ? e2 : e3;
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
