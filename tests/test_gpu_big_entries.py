@@ -138,6 +138,34 @@ def test_one_large_lz4_frame_is_decoded_block_parallel(codec, cls):
         assert np.array_equal(out1[i], p) and np.array_equal(out0[i], p), i
 
 
+@pytest.mark.parametrize("level", [1, 3])
+@pytest.mark.parametrize("cls", [dg.TEXT, dg.RECORDS, dg.RANDOM, dg.RUNS])
+def test_one_large_zstd_frame_is_decoded_block_parallel(codec, cls, level):
+    """What the reference writer produces for a large Zstandard entry is ONE frame of blocks of up to 128 KiB (lib/zpack_write.c:179,
+    ZSTD_compressCCtx).  The host read path decodes the blocks' sequences and literals side by side — repeat offsets against symbols
+    that a scan over the blocks resolves, Treeless literals with the tree of the block they inherit from — and resolves every
+    output byte by pointer doubling (zstd_pj.h): frames made by libzstd of every corpus class and two levels — bytes equal the
+    plaintext and the one-wave decoder's, the hash is the real xxHash's, the counters say that the block-parallel path ran."""
+    sizes = [2 * M, 5 * M + 12345, 9 * M + 1]
+    plains = [dg.fill(cls, 78, i, n) for i, n in enumerate(sizes)]
+    pay = [np.frombuffer(dg.compress(METHOD_ZSTD, level, p), dtype=np.uint8) for p in plains]
+    want = [dg.xxh3(p) for p in plains]
+    arc, offs, cs = _image(pay)
+    d = _descs(offs, cs, sizes, want, [(METHOD_ZSTD, level)] * len(sizes))
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    r1, out1 = codec.decode_batch_host(arc, d)
+    st = codec.decode_stats()
+    assert st["frame_parallel_entries"] == len(sizes), st
+    codec.set_option(OPT_DEC_SPLIT_MIN, 0)
+    r0, out0 = codec.decode_batch_host(arc, d)
+    assert codec.decode_stats()["frame_parallel_entries"] == 0
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    for r in (r0, r1):
+        assert (r["status"] == 0).all() and [int(h) for h in r["hash"]] == want and [int(x) for x in r["produced"]] == sizes, r
+    for i, p in enumerate(plains):
+        assert np.array_equal(out1[i], p) and np.array_equal(out0[i], p), i
+
+
 def test_reference_made_large_lz4_recipes_block_parallel(codec, golden_dir):
     """The LZ4 entries of tests/golden/recipes_big.json (64 MiB text, 64 MiB records, 512 MiB text; sizes, frame checksums and content
     hashes recorded from the compiled reference by tests/golden/make_golden_big.py) through the host read path: every one takes the

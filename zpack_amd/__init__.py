@@ -168,7 +168,7 @@ class Codec:
         return dict(stored=a[0], zstd=a[1], lz4=a[2], zstd_two_stage=a[3], zstd_fused=a[4], fse_watchdog=a[5], fse_budget=a[6],
                     zstd_arena_refused=bool(a[7] >> 31), retried_lz4=b[0], retried_zstd=b[1],
                     lz4_long_runs=b[3],
-                    frame_parallel_entries=b[5], frame_parallel_frames=b[6])
+                    frame_parallel_entries=b[5], frame_parallel_frames=b[6], zstd_blocks_flags=b[7])
 
     def debug_fetch(self, what, offset, count, dtype):
         a = np.zeros(count, dtype=dtype)

@@ -34,6 +34,7 @@
 #include "zstd_fse4.h"
 #include "zstd_ring.h"
 #include "lz4_pj.h"
+#include "zstd_pj.h"
 
 using namespace zpk;
 
@@ -588,6 +589,10 @@ struct zpk_codec {
     void* d_pj_masks = nullptr;  u64 pj_masks_cap = 0;
     void* d_pj_S = nullptr;      u64 pj_S_cap = 0;
     u32*  d_pj_flags = nullptr;
+    u32   zpj_last_err = 0;                          // developer: the flag word of the most recent large Zstandard frame (why it went to the one-wave decoder)
+    void* d_zpj_blocks = nullptr; u64 zpj_blocks_cap = 0; // large single Zstandard frames (zstd_pj.h): block table; work items, states, final histories; sequence positions
+    void* d_zpj_aux = nullptr;    u64 zpj_aux_cap = 0;
+    void* d_zpj_pos = nullptr;    u64 zpj_pos_cap = 0;
     hipStream_t s_left = nullptr;                // decode batches: k_lz4_left (the LZ4 entries that are mostly runs) beside k_lz4_wave
     hipEvent_t ev_lfork = nullptr, ev_ljoin = nullptr;
     volatile u32* h_seen = nullptr;              // pinned: the work-list counts of an earlier device batch (what the next one probably holds)
@@ -710,6 +715,7 @@ void zpk_codec_destroy(zpk_codec* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (u32 k = 0; k < ZPK_PJ_MAX_CHUNKS; k++) if (c->pj_ev[k]) (void)hipEventDestroy(c->pj_ev[k]);
+    (void)hipFree(c->d_zpj_blocks); (void)hipFree(c->d_zpj_aux); (void)hipFree(c->d_zpj_pos);
     (void)hipFree(c->d_pj_blocks); (void)hipFree(c->d_pj_recs); (void)hipFree(c->d_pj_masks); (void)hipFree(c->d_pj_S); (void)hipFree(c->d_pj_flags);
     if (c->s_left) (void)hipStreamDestroy(c->s_left);
     if (c->ev_lfork) (void)hipEventDestroy(c->ev_lfork);
@@ -1459,36 +1465,21 @@ static bool walk_lz4_single(const u8* p, u64 comp, u64 uncomp, std::vector<PjBlo
     return q == comp && blocks.size() >= ZPK_PJ_MIN_BLOCKS;
 }
 
-// -> ZPK_OK with redo = 0: the entry is decoded, hashed and delivered; redo = 1: not this path's (the one-wave decoder decides)
-static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_decode_desc& d, const std::vector<PjBlock>& blocks, int independent,
-                                 uint8_t* dst_ptr, zpk_decode_result& result, u8& redo)
+// The common second half of the block-parallel readers (lz4_pj.h, zstd_pj.h): the blocks' references exist per chunk through `init`, the
+// block table `hb` (output offsets) is on the host.  Chunks of ZPK_PJ_CHUNK_BLOCKS blocks are resolved one after the other, hashed and
+// downloaded beside that.  accept_mismatch: a wrong XXH3 is this path's verdict (LZ4: everything about the frame was checked); otherwise
+// the one-wave decoder decides.
+extern "C++" {
+template <class InitFn>
+static int pj_finish(zpk_codec* c, const zpk_decode_desc& d, const std::vector<PjBlock>& hb, u64 gather_src_size, InitFn init, bool accept_mismatch,
+                     uint8_t* dst_ptr, zpk_decode_result& result, u8& redo)
 {
-    redo = 1;
-    const u64 nb = blocks.size(), n = d.uncomp_size;
-    const u64 total_recs = (u64)blocks.back().rec_base + ((blocks.back().comp_size >> 31) ? 0 : (blocks.back().comp_size / 3 + 2));
-    int rc;
-    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, d.comp_size + ZPK_SRC_SLACK)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, n + 16)) ||
-        (rc = grow(c, &c->d_pj_blocks, &c->pj_blocks_cap, nb * sizeof(PjBlock))) || (rc = grow(c, &c->d_pj_recs, &c->pj_recs_cap, (total_recs + 64) * 8)) ||
-        (rc = grow(c, &c->d_pj_masks, &c->pj_masks_cap, nb * (PJ_BLOCK / 8))) || (rc = grow(c, &c->d_pj_S, &c->pj_S_cap, n * 4 + 64))) { c->err[0] = 0; return ZPK_OK; }     // no memory for the scratch: the one-wave decoder
-    if (!c->d_pj_flags && hipMalloc((void**)&c->d_pj_flags, 256) != hipSuccess) { c->d_pj_flags = nullptr; (void)hipGetLastError(); return ZPK_OK; }
+    const u64 nb = hb.size(), n = d.uncomp_size;
     hipStream_t st = c->stream;
-    hipError_t e = hipMemcpyAsync(c->d_src, archive + d.src_offset, d.comp_size, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(c->d_pj_blocks, blocks.data(), nb * sizeof(PjBlock), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_pj_flags, 0, 256, st);
-    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
     PjBlock* const B = (PjBlock*)c->d_pj_blocks;
     u32* const S = (u32*)c->d_pj_S;
-    hipLaunchKernelGGL(k_pj_parse, dim3((u32)nb), dim3(64), 0, st, (const u8*)c->d_src, d.comp_size, B, (u32)nb, (u64*)c->d_pj_recs, (u32*)c->d_pj_masks, c->d_pj_flags);
-    hipLaunchKernelGGL(k_pj_scan, dim3(1), dim3(64), 0, st, B, (u32)nb, c->d_pj_flags);
-    u32 hf[4] = {0, 0, 0, 0};
-    // the verdict of the parse and the block table with its output offsets, back on the host (the one round trip of this path):
-    // chunk k = blocks [k * ZPK_PJ_CHUNK_BLOCKS, ...) = output bytes [lo_k, hi_k)
-    std::vector<PjBlock> hb(nb);
-    e = hipMemcpyAsync(hf, c->d_pj_flags, sizeof(hf), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), B, nb * sizeof(PjBlock), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
-    if (hf[PJ_ERR] || (((u64)hf[PJ_TOTAL + 1] << 32) | hf[PJ_TOTAL]) != n) return ZPK_OK;          // irregular, or the sizes do not add up
+    hipError_t e;
+    int rc;
     const u64 nchunks = (nb + ZPK_PJ_CHUNK_BLOCKS - 1) / ZPK_PJ_CHUNK_BLOCKS;
     if (nchunks > ZPK_PJ_MAX_CHUNKS) return ZPK_OK;
     for (u64 k = 0; k < nchunks; k++) if (!c->pj_ev[k] && hipEventCreateWithFlags(&c->pj_ev[k], hipEventDisableTiming) != hipSuccess) { c->pj_ev[k] = nullptr; return ZPK_OK; }
@@ -1507,7 +1498,7 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
     u64* const d_state = d_hash + 8;
     zpk_span span; span.off = 0; span.len = n; span.part_base = 0;
     e = hipMemcpyAsync(d_span, &span, sizeof(span), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
     // ---- the output to the caller's buffer starts while the chunks are still being resolved: d2h_scatter (pinned staging, the copy of piece
     // j + 1 on the bus while piece j is copied out by a few threads) runs on a helper thread and takes a piece as soon as the chunks under it
     // have been ENQUEUED (their events recorded).  The bytes are the entry's whatever the verdict (lib/zpack_read.c:466-468 leaves
@@ -1544,11 +1535,11 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
         const u64 lo = hb[b0].out_off, hi = chunk_hi[k];
         const u32 grid = (u32)((hi - (lo & ~3ull) + 1023) / 1024), jgrid = (u32)((hi - lo + 1023) / 1024);
         (void)hipMemsetAsync(c->d_pj_flags + PJ_ROUND0, 0, PJ_MAX_ROUNDS * 4, st);
-        hipLaunchKernelGGL(k_pj_init, dim3(b1 - b0), dim3(256), 0, st, (const PjBlock*)B, b0, (u32)nb, (const u64*)c->d_pj_recs, (const u32*)c->d_pj_masks, S, n, c->d_pj_flags, independent);
+        init(b0, b1, st);
         if (grid) {
             for (u32 r = 0; r < PJ_MAX_ROUNDS; r++)
                 hipLaunchKernelGGL(k_pj_jump, dim3(jgrid), dim3(256), 0, st, S, (const PjBlock*)B, b0, b1, (u32)nb, c->d_pj_flags, r);
-            hipLaunchKernelGGL(k_pj_gather, dim3(grid), dim3(256), 0, st, (const u32*)S, (const PjBlock*)B, b0, b1, (u32)nb, (const u8*)c->d_src, d.comp_size, c->d_dst, c->d_pj_flags);
+            hipLaunchKernelGGL(k_pj_gather, dim3(grid), dim3(256), 0, st, (const u32*)S, (const PjBlock*)B, b0, b1, (u32)nb, (const u8*)c->d_src, gather_src_size, c->d_dst, c->d_pj_flags);
         }
         if (hipEventRecord(c->pj_ev[k], st) != hipSuccess || hipStreamWaitEvent(sh, c->pj_ev[k], 0) != hipSuccess) { launch_failed = true; break; }
         enqueued.store(k + 1, std::memory_order_release);
@@ -1566,20 +1557,204 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
     if (e != hipSuccess || dn_rc != ZPK_OK || dn_e != hipSuccess) {
         (void)hipDeviceSynchronize();
         if (dn_rc != ZPK_OK && !launch_failed) return dn_rc;
-        snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e != hipSuccess ? e : dn_e));
+        snprintf(c->err, sizeof(c->err), "large frame: %s", hipGetErrorString(e != hipSuccess ? e : dn_e));
         return ZPK_E_LAUNCH;
     }
     e = hipStreamSynchronize(c->s_dn);
     const hipError_t e2 = hipStreamSynchronize(sh), e3 = hipStreamSynchronize(st);
     if (e == hipSuccess) e = e2 != hipSuccess ? e2 : e3;
-    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
     if ((u32)c->h_pj[1] != 0) return ZPK_OK;                                                       // PJ_ERR: something was irregular after all
     const u64 h = c->h_pj[0];
     result.hash = h; result.produced = n; result.detail = 0;
-    result.status = ((d.flags & ZPK_DF_SKIP_HASH) || h == d.expect_hash) ? 0 : 15;                  // ZPACK_ERROR_FILE_HASH_MISMATCH, lib/zpack_read.c:467
+    const bool hash_ok = (d.flags & ZPK_DF_SKIP_HASH) || h == d.expect_hash;
+    if (!hash_ok && !accept_mismatch) return ZPK_OK;                                               // (the one-wave decoder gives this entry's verdict)
+    result.status = hash_ok ? 0 : 15;                                                              // ZPACK_ERROR_FILE_HASH_MISMATCH, lib/zpack_read.c:467
     c->big_last[0]++; c->big_last[1] += (u32)nb;
     redo = 0;
     return ZPK_OK;
+}
+
+}   // extern "C++"
+
+// -> ZPK_OK with redo = 0: the entry is decoded, hashed and delivered; redo = 1: not this path's (the one-wave decoder decides)
+static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_decode_desc& d, const std::vector<PjBlock>& blocks, int independent,
+                                 uint8_t* dst_ptr, zpk_decode_result& result, u8& redo)
+{
+    redo = 1;
+    const u64 nb = blocks.size(), n = d.uncomp_size;
+    const u64 total_recs = (u64)blocks.back().rec_base + ((blocks.back().comp_size >> 31) ? 0 : (blocks.back().comp_size / 3 + 2));
+    int rc;
+    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, d.comp_size + ZPK_SRC_SLACK)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, n + 16)) ||
+        (rc = grow(c, &c->d_pj_blocks, &c->pj_blocks_cap, nb * sizeof(PjBlock))) || (rc = grow(c, &c->d_pj_recs, &c->pj_recs_cap, (total_recs + 64) * 8)) ||
+        (rc = grow(c, &c->d_pj_masks, &c->pj_masks_cap, nb * (PJ_BLOCK / 8))) || (rc = grow(c, &c->d_pj_S, &c->pj_S_cap, n * 4 + 64))) { c->err[0] = 0; return ZPK_OK; }     // no memory for the scratch: the one-wave decoder
+    if (!c->d_pj_flags && hipMalloc((void**)&c->d_pj_flags, 256) != hipSuccess) { c->d_pj_flags = nullptr; (void)hipGetLastError(); return ZPK_OK; }
+    hipStream_t st = c->stream;
+    hipError_t e = hipMemcpyAsync(c->d_src, archive + d.src_offset, d.comp_size, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_pj_blocks, blocks.data(), nb * sizeof(PjBlock), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_pj_flags, 0, 256, st);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    PjBlock* const B = (PjBlock*)c->d_pj_blocks;
+    u32* const S = (u32*)c->d_pj_S;
+    hipLaunchKernelGGL(k_pj_parse, dim3((u32)nb), dim3(64), 0, st, (const u8*)c->d_src, d.comp_size, B, (u32)nb, (u64*)c->d_pj_recs, (u32*)c->d_pj_masks, c->d_pj_flags);
+    hipLaunchKernelGGL(k_pj_scan, dim3(1), dim3(64), 0, st, B, (u32)nb, c->d_pj_flags);
+    u32 hf[4] = {0, 0, 0, 0};
+    // the verdict of the parse and the block table with its output offsets, back on the host (the one round trip of this path):
+    // chunk k = blocks [k * ZPK_PJ_CHUNK_BLOCKS, ...) = output bytes [lo_k, hi_k)
+    std::vector<PjBlock> hb(nb);
+    e = hipMemcpyAsync(hf, c->d_pj_flags, sizeof(hf), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), B, nb * sizeof(PjBlock), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large LZ4 frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    if (hf[PJ_ERR] || (((u64)hf[PJ_TOTAL + 1] << 32) | hf[PJ_TOTAL]) != n) return ZPK_OK;          // irregular, or the sizes do not add up
+    auto init = [&](u32 b0, u32 b1, hipStream_t s2) {
+        hipLaunchKernelGGL(k_pj_init, dim3(b1 - b0), dim3(256), 0, s2, (const PjBlock*)B, b0, (u32)nb, (const u64*)c->d_pj_recs, (const u32*)c->d_pj_masks, S, n, c->d_pj_flags, independent);
+    };
+    return pj_finish(c, d, hb, d.comp_size, init, true, dst_ptr, result, redo);
+}
+
+// ONE Zstandard frame as ZSTD_compressCCtx writes it (lib/zpack_write.c:179): no dictionary, no checksum, its content size (if stated) the
+// entry's, a window of at most 128 MiB, no Repeat_Mode table, every Treeless block behind a block with a tree, >= ZPK_PJ_MIN_BLOCKS
+// blocks, nothing behind the last block -> the block table of zstd_pj.h.  slots = sequence slots (a block owns nseq + 1), lit_total =
+// bytes of the literal arena.
+static bool walk_zstd_single(const u8* p, u64 comp, u64 uncomp, std::vector<ZpjBlock>& blocks, u64& slots, u64& lit_total)
+{
+    blocks.clear(); slots = 0; lit_total = 0;
+    if (comp < 9 || hrd32(p) != 0xFD2FB528u) return false;
+    u64 q = 4;
+    const u32 fhd = p[q++];
+    const u32 fcs_flag = fhd >> 6, single = (fhd >> 5) & 1;
+    if (fhd & 0x0F) return false;                                   // reserved bit, content checksum, dictionary: the one-wave decoder's
+    if (!single) { const u32 wdesc = p[q++]; if (10 + (wdesc >> 3) > 27) return false; }
+    const u32 fn = fcs_flag == 0 ? (single ? 1u : 0u) : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+    if (comp - q < fn) return false;
+    if (fn) { u64 fcs = 0; for (u32 i = 0; i < fn; i++) fcs |= (u64)p[q + i] << (8 * i); if (fn == 2) fcs += 256; if (fcs != uncomp) return false; q += fn; }
+    u32 tree = ZPJ_NONE;
+    for (;;) {
+        if (comp - q < 3) return false;
+        const u32 bh = (u32)p[q] | ((u32)p[q + 1] << 8) | ((u32)p[q + 2] << 16);
+        const u32 last = bh & 1, bt = (bh >> 1) & 3, bs = bh >> 3;
+        ZpjBlock B; memset(&B, 0, sizeof(B));
+        B.hdr_off = (u32)q; B.type = bt; B.size = bs; B.tree_src = ZPJ_NONE;
+        if (bt == 3 || bs > ZPJ_BLOCK || q > 0x7FFFFF00ull) return false;
+        const u64 body = bt == 1 ? 1 : bs;
+        if (comp - q - 3 < body) return false;
+        if (bt == 2) {
+            const u8* const b = p + q + 3;
+            if (bs < 3) return false;
+            const u32 b0 = b[0], lt = b0 & 3, fmt = (b0 >> 2) & 3;
+            u32 hl, regen, csize;
+            if (lt < 2) {
+                if ((fmt & 1) == 0) { hl = 1; regen = b0 >> 3; }
+                else if (fmt == 1) { hl = 2; regen = (b0 >> 4) | ((u32)b[1] << 4); }
+                else { hl = 3; regen = (b0 >> 4) | ((u32)b[1] << 4) | ((u32)b[2] << 12); }
+                csize = lt == 0 ? regen : 1u;
+            } else {
+                if (bs < 5) return false;
+                const u64 v = hrd32(b);
+                if (fmt < 2) { hl = 3; regen = (u32)(v >> 4) & 0x3FF; csize = (u32)(v >> 14) & 0x3FF; }
+                else if (fmt == 2) { hl = 4; regen = (u32)(v >> 4) & 0x3FFF; csize = (u32)(v >> 18); }
+                else { hl = 5; regen = (u32)(v >> 4) & 0x3FFFF; csize = (u32)(v >> 22) | ((u32)b[4] << 10); }
+            }
+            if (regen > ZPJ_BLOCK || (u64)hl + csize > bs) return false;
+            B.lit_type = lt; B.lit_size = regen; B.lit_used = hl + csize;
+            if (lt == 2) tree = (u32)blocks.size();
+            if (lt == 3) { if (tree == ZPJ_NONE) return false; B.tree_src = tree; }
+            if (lt < 2) B.lit_ref = (u32)(q + 3 + hl);
+            else { B.lit_base = (u32)lit_total; lit_total += ((u64)regen + 15) / 16 * 16 + 64; }
+            u64 o = B.lit_used;
+            if (bs - o < 1) return false;
+            u64 nseq = b[o];
+            if (nseq == 0) { if (bs - o != 1) return false; }
+            else {
+                if (nseq < 128) o += 1;
+                else if (nseq < 255) { if (bs - o < 2) return false; nseq = ((nseq - 128) << 8) + b[o + 1]; o += 2; }
+                else { if (bs - o < 3) return false; nseq = (u64)b[o + 1] + ((u64)b[o + 2] << 8) + 0x7F00; o += 3; }
+                if (bs - o < 1) return false;
+                const u32 modes = b[o];
+                if ((modes & 3) || ((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3) return false;
+            }
+            B.nseq = (u32)nseq;
+            B.seq_base = (u32)slots;
+            slots += nseq + 1;
+        }
+        blocks.push_back(B);
+        q += 3 + body;
+        if (last) break;
+        if (slots > 0x7FFFFF00ull || lit_total > 0x70000000ull) return false;
+    }
+    if (q != comp || blocks.size() < ZPK_PJ_MIN_BLOCKS) return false;
+    return comp + lit_total + 1024 < 0x7FFFFF00ull;
+}
+
+// -> ZPK_OK with redo = 0: the entry is decoded, its XXH3 is the expected one, the bytes are delivered; redo = 1: not this path's
+static int decode_big_zstd_single(zpk_codec* c, const u8* archive, const zpk_decode_desc& d, std::vector<ZpjBlock>& blocks, u64 slots, u64 lit_total,
+                                  uint8_t* dst_ptr, zpk_decode_result& result, u8& redo)
+{
+    redo = 1;
+    const u64 nb = blocks.size(), n = d.uncomp_size;
+    const u64 arena_off = (d.comp_size + 64 + 255) & ~255ull;
+    for (u64 b = 0; b < nb; b++) if (blocks[b].type == 2 && blocks[b].lit_type >= 2) blocks[b].lit_ref = (u32)(arena_off + blocks[b].lit_base);
+    // work items of the sequence stage: the compressed blocks that have sequences
+    std::vector<zpk_decode_desc> items(nb);
+    std::vector<u32> list;
+    memset(items.data(), 0, nb * sizeof(zpk_decode_desc));
+    for (u64 b = 0; b < nb; b++) {
+        if (blocks[b].type != 2 || blocks[b].nseq == 0) continue;
+        items[b].src_offset = blocks[b].hdr_off; items[b].comp_size = 3ull + blocks[b].size;
+        items[b].dst_offset = 8ull * blocks[b].seq_base; items[b].dst_capacity = 8ull * blocks[b].nseq; items[b].method = ZPK_METHOD_ZSTD;
+        list.push_back((u32)b);
+    }
+    const u64 aux_desc = 0, aux_list = (nb * sizeof(zpk_decode_desc) + 255) & ~255ull, aux_state = aux_list + ((nb * 4 + 255) & ~255ull),
+              aux_rep = aux_state + ((nb * 4 + 255) & ~255ull), aux_size = aux_rep + nb * 12 + 256;
+    int rc;
+    if ((rc = grow(c, (void**)&c->d_src, &c->src_cap, arena_off + lit_total + ZPK_SRC_SLACK)) || (rc = grow(c, (void**)&c->d_dst, &c->dst_cap, n + 16)) ||
+        (rc = grow(c, &c->d_pj_blocks, &c->pj_blocks_cap, nb * sizeof(PjBlock))) || (rc = grow(c, &c->d_zpj_blocks, &c->zpj_blocks_cap, nb * sizeof(ZpjBlock))) ||
+        (rc = grow(c, &c->d_zpj_aux, &c->zpj_aux_cap, aux_size)) || (rc = grow(c, &c->d_pj_recs, &c->pj_recs_cap, (slots + 64) * 8)) ||
+        (rc = grow(c, &c->d_zpj_pos, &c->zpj_pos_cap, (slots + 64) * 8)) || (rc = grow(c, &c->d_pj_masks, &c->pj_masks_cap, nb * (ZPJ_BLOCK / 8))) ||
+        (rc = grow(c, &c->d_pj_S, &c->pj_S_cap, n * 4 + 64))) { c->err[0] = 0; return ZPK_OK; }        // no memory for the scratch: the one-wave decoder
+    if (!c->d_pj_flags && hipMalloc((void**)&c->d_pj_flags, 256) != hipSuccess) { c->d_pj_flags = nullptr; (void)hipGetLastError(); return ZPK_OK; }
+    hipStream_t st = c->stream;
+    u8* const aux = (u8*)c->d_zpj_aux;
+    u32 hflags[64]; memset(hflags, 0, sizeof(hflags));
+    hflags[ZPJ_CNT + ZF_COUNT_WORD] = (u32)list.size();
+    std::vector<PjBlock> hb(nb);
+    memset(hb.data(), 0, nb * sizeof(PjBlock));
+    hipError_t e = hipMemcpyAsync(c->d_src, archive + d.src_offset, d.comp_size, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_zpj_blocks, blocks.data(), nb * sizeof(ZpjBlock), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_pj_blocks, hb.data(), nb * sizeof(PjBlock), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(aux + aux_desc, items.data(), nb * sizeof(zpk_decode_desc), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && !list.empty()) e = hipMemcpyAsync(aux + aux_list, list.data(), list.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(aux + aux_state, 0, aux_size - aux_state, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_pj_flags, hflags, sizeof(hflags), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "H2D: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    PjBlock* const B = (PjBlock*)c->d_pj_blocks;
+    ZpjBlock* const ZB = (ZpjBlock*)c->d_zpj_blocks;
+    u32* const S = (u32*)c->d_pj_S;
+    u32* const state = (u32*)(aux + aux_state);
+    u32* const rep_out = (u32*)(aux + aux_rep);
+    if (!list.empty()) {
+        const u32 rows = (u32)list.size();
+        const u32 grid = (rows + ZF_ROWS - 1) / ZF_ROWS < ZF_GRID_MAX ? (rows + ZF_ROWS - 1) / ZF_ROWS : ZF_GRID_MAX;
+        hipLaunchKernelGGL(k_zstd_fse_blocks, dim3(grid), dim3(64), 0, st, (const u8*)c->d_src, (const zpk_decode_desc*)(aux + aux_desc), (const u32*)(aux + aux_list),
+                           c->d_pj_flags + ZPJ_CNT, (u64*)c->d_pj_recs, state, rep_out);
+    }
+    hipLaunchKernelGGL(k_zpj_lit, dim3((u32)nb), dim3(64), 0, st, c->d_src, arena_off + lit_total, arena_off, (const ZpjBlock*)ZB, (u32)nb, c->d_pj_flags);
+    hipLaunchKernelGGL(k_zpj_reps, dim3(1), dim3(64), 0, st, ZB, (u32)nb, (const u32*)state, (const u32*)rep_out, c->d_pj_flags);
+    hipLaunchKernelGGL(k_zpj_pos, dim3((u32)nb), dim3(256), 0, st, (const ZpjBlock*)ZB, B, (u32)nb, (const u64*)c->d_pj_recs, (u64*)c->d_zpj_pos, (u32*)c->d_pj_masks, c->d_pj_flags);
+    hipLaunchKernelGGL(k_pj_scan, dim3(1), dim3(64), 0, st, B, (u32)nb, c->d_pj_flags);
+    u32 hf[4] = {0, 0, 0, 0};
+    e = hipMemcpyAsync(hf, c->d_pj_flags, sizeof(hf), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), B, nb * sizeof(PjBlock), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "large Zstandard frame: %s", hipGetErrorString(e)); return ZPK_E_LAUNCH; }
+    c->zpj_last_err = hf[PJ_ERR] | ((((u64)hf[PJ_TOTAL + 1] << 32) | hf[PJ_TOTAL]) != n ? 0x40000000u : 0u);
+    if (hf[PJ_ERR] || (((u64)hf[PJ_TOTAL + 1] << 32) | hf[PJ_TOTAL]) != n) return ZPK_OK;          // irregular, or the sizes do not add up
+    auto init = [&](u32 b0, u32 b1, hipStream_t s2) {
+        hipLaunchKernelGGL(k_zpj_init, dim3(b1 - b0), dim3(256), 0, s2, (const ZpjBlock*)ZB, (const PjBlock*)B, b0, (u32)nb, (const u64*)c->d_pj_recs, (const u64*)c->d_zpj_pos,
+                           (const u32*)c->d_pj_masks, S, n, c->d_pj_flags);
+    };
+    return pj_finish(c, d, hb, arena_off + lit_total, init, false, dst_ptr, result, redo);
 }
 
 // the frames of entries [g0, g1) of `be` as one device batch; redo[k] = 1: entry k takes the serial path after all
@@ -1670,8 +1845,8 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
     // ---- which entries are sequences of frames worth decoding frame-parallel ----
     std::vector<BigEntry> be;
     std::vector<BigSub> subs;
-    struct PjEntry { u64 idx; std::vector<PjBlock> blocks; int independent; };
-    std::vector<PjEntry> pj;                                                          // large single LZ4 frames (lz4_pj.h)
+    struct PjEntry { u64 idx; std::vector<PjBlock> blocks; int independent; std::vector<ZpjBlock> zblocks; u64 slots, lit_total; };
+    std::vector<PjEntry> pj;                                                          // large single frames (lz4_pj.h, zstd_pj.h)
     if (archive && c->dec_split_min != ~0ull) {
         try {
             for (u64 i = 0; i < n; i++) {
@@ -1692,11 +1867,17 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
                 } else if (d.method == ZPK_METHOD_LZ4) {
                     ok = walk_lz4_frames(archive + d.src_offset, d.comp_size, d.uncomp_size, subs);
                     if (!ok) {                                                        // ONE frame (what the reference writes): block-parallel
-                        PjEntry P; P.idx = i; P.independent = 0;
+                        PjEntry P; P.idx = i; P.independent = 0; P.slots = P.lit_total = 0;
                         if (walk_lz4_single(archive + d.src_offset, d.comp_size, d.uncomp_size, P.blocks, P.independent)) pj.push_back(std::move(P));
                     }
                 }
-                else ok = walk_zstd_frames(archive + d.src_offset, d.comp_size, d.uncomp_size, subs);
+                else {
+                    ok = walk_zstd_frames(archive + d.src_offset, d.comp_size, d.uncomp_size, subs);
+                    if (!ok) {                                                        // ONE frame (what the reference writes): block-parallel
+                        PjEntry P; P.idx = i; P.independent = 0; P.slots = P.lit_total = 0;
+                        if (walk_zstd_single(archive + d.src_offset, d.comp_size, d.uncomp_size, P.zblocks, P.slots, P.lit_total)) pj.push_back(std::move(P));
+                    }
+                }
                 if (ok) be.push_back(BigEntry{ i, (u64)s0, (u64)(subs.size() - s0) });
             }
         } catch (...) { be.clear(); subs.clear(); pj.clear(); }                       // out of host memory for the plan: the usual path
@@ -1719,7 +1900,10 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
         for (u64 k = 0; k < be.size(); k++) if (!redo[k]) is_big[be[k].idx] = 1;
         for (u64 k = 0; k < pj.size() && rc == ZPK_OK; k++) {                         // one large frame at a time: each fills the chip
             u8 again = 1;
-            rc = decode_big_lz4_single(c, archive, desc[pj[k].idx], pj[k].blocks, pj[k].independent, dst_ptrs[pj[k].idx], results[pj[k].idx], again);
+            if (desc[pj[k].idx].method == ZPK_METHOD_LZ4)
+                rc = decode_big_lz4_single(c, archive, desc[pj[k].idx], pj[k].blocks, pj[k].independent, dst_ptrs[pj[k].idx], results[pj[k].idx], again);
+            else
+                rc = decode_big_zstd_single(c, archive, desc[pj[k].idx], pj[k].zblocks, pj[k].slots, pj[k].lit_total, dst_ptrs[pj[k].idx], results[pj[k].idx], again);
             if (rc == ZPK_OK && !again) is_big[pj[k].idx] = 1;
         }
         std::vector<u64> rest;
@@ -1873,6 +2057,7 @@ int zpk_codec_decode_stats2(zpk_codec* c, uint32_t out[16])
     out[0] = h[C_RETRY_LZ4]; out[1] = h[C_RETRY_ZSTD];
     out[2] = 0; out[3] = h[C_LZ4_LEFT]; out[4] = 0;      // [3]: LZ4 entries that are mostly runs, decoded by k_lz4_left (the two-stage path of round 4 is gone: [2], [4] read 0)
     out[5] = c->big_last[0]; out[6] = c->big_last[1];
+    out[7] = c->zpj_last_err;                              // why the most recent large Zstandard frame was NOT finished block-parallel (0: it was, or none came)
     return ZPK_OK;
 }
 

@@ -203,12 +203,20 @@ __device__ __forceinline__ int zf_read_ncount(const u128& stage, u32 o, u32 size
 enum { ZF_NEED_ENTRY = 0, ZF_NEED_FRAME = 1, ZF_NEED_BLOCK = 2, ZF_DECODING = 3, ZF_DONE = 4 };
 
 // state[e] = 1: entry e's sequences are in the arena (region of its output slot, 8 bytes per sequence); 0: not.
-__global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
-                                                 const u32* __restrict__ list, u32* __restrict__ counters,
-                                                 u64* __restrict__ arena, u32* __restrict__ state)
+//
+// BLOCKS (zstd_pj.h: the blocks of ONE large frame side by side): a work item is one compressed BLOCK — desc[e].src_offset = its
+// 3-byte block header, comp_size = 3 + Block_Size, its arena region = desc[e].dst_offset / 8, dst_capacity / 8 sequences — not an
+// entry: no frame header, the item ends with the block.  What a block inherits from the blocks before it are the three repeat
+// offsets, unknown here: the row starts with three SYMBOLS instead (ZF_SYM(1..3): values >= 2^27, where no real offset of this
+// path lies; "rep0 - 1" counts down inside the symbol), offsets that come from the inherited history leave as symbols, and the
+// block's final history goes to rep_out[3 e ..] for the scan over the blocks that gives every symbol its value (k_zpj_reps).
+#define ZF_SYM_SHIFT 27
+#define ZF_SYM(j) (((u32)(j) << ZF_SYM_SHIFT) | ((1u << ZF_SYM_SHIFT) - 1u))
+template <bool BLOCKS>
+__device__ __forceinline__ void zstd_fse_rows(ZfShared& sh, const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
+                                              const u32* __restrict__ list, u32* __restrict__ counters,
+                                              u64* __restrict__ arena, u32* __restrict__ state, u32* __restrict__ rep_out)
 {
-    if (counters[ZF_COUNT_WORD] == 0) return;        // no Zstandard entry in the batch
-    __shared__ ZfShared sh;
     const int lane = lane_id();
     const int row = lane >> 4, sub = lane & 15;
     ZPK_LDS ZfRow* const R = (ZPK_LDS ZfRow*)&sh.row[row];
@@ -289,6 +297,10 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                     seq_n = 0; bad = false; badv = 0;
                     row_deadline = __builtin_amdgcn_s_memrealtime() + watchdog_budget(d.comp_size + d.dst_capacity);
                     phase = ZF_NEED_FRAME;
+                    if constexpr (BLOCKS) {                              // the item IS a block: no frame header, inherited history as symbols
+                        rep0 = ZF_SYM(1); rep1 = ZF_SYM(2); rep2 = ZF_SYM(3); tables_valid = false; cksum = false;
+                        phase = ZF_NEED_BLOCK;
+                    }
                 }
                 if (phase == ZF_NEED_FRAME) {
                     // frame header, as zstd_decode_wave
@@ -296,7 +308,10 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                         const u32 rem = seq_n & (ZF_SEQBUF - 1u);
                         if (!bad && rem && (u32)sub < rem) arena[a_base + (seq_n - 1u) - (u32)sub] = ((u64)acc_hi << 32) | acc_lo;
                         lane0_guard();
-                        if (sub == 0) { state[e] = bad ? 0u : 1u; if (!bad) atomicAdd(&counters[ZF_WATCHDOG_WORD + 2], 1u); }
+                        if (sub == 0) {
+                            if constexpr (BLOCKS) { rep_out[3u * e] = rep0; rep_out[3u * e + 1u] = rep1; rep_out[3u * e + 2u] = rep2; }
+                            state[e] = bad ? 0u : 1u; if (!bad) atomicAdd(&counters[ZF_WATCHDOG_WORD + 2], 1u);
+                        }
                         lane0_guard();
                         phase = ZF_NEED_ENTRY;
                         continue;
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                 if (iend - ip < 3) { bad = true; ip = iend; phase = ZF_NEED_FRAME; continue; }
                 const u32 bh = (u32)ld8(ip) | ((u32)ld8(ip + 1) << 8) | ((u32)ld8(ip + 2) << 16);
                 ip += 3;
-                last_block = bh & 1;
+                last_block = BLOCKS ? true : (bh & 1) != 0;
                 const u32 btype = (bh >> 1) & 3; const u64 bsize = bh >> 3;
                 bool ok = btype != 3;
                 u64 adv = btype == 1 ? 1 : bsize;
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
                 // what does not fit the packing (or is corrupt) sends the entry to the fused decoder at the end of the block
                 // (an offset is >= 1 by construction and repeat offsets were checked when they were new; match and literal lengths cannot
                 // reach their 18 / 17 bits: codes <= 52 / 35 give at most 131 074 / 131 071)
-                badv |= val >> ZF_SEQ_OFF_BITS;                      // (offset values of 2^29 .. 2^29 + 2 would still fit: they go to the fused decoder too)
+                badv |= val >> (BLOCKS ? ZF_SYM_SHIFT : ZF_SEQ_OFF_BITS);   // (offset values of 2^29 .. 2^29 + 2 would still fit: they go to the fused decoder too; BLOCKS: real offsets stay below the symbols)
                 {   // The row keeps its last sequences in REGISTERS, as a shift register along its lanes: every step the packed values move
                     // one lane up (DPP row_shr:1) and lane 0 — which has no lane below it and therefore keeps the `old` operand — takes
                     // the new one.  After eight steps lane j holds sequence (seq_n - 1 - j): no LDS, no exec mask, two instructions.
@@ -551,6 +566,23 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
+                                                 const u32* __restrict__ list, u32* __restrict__ counters,
+                                                 u64* __restrict__ arena, u32* __restrict__ state)
+{
+    if (counters[ZF_COUNT_WORD] == 0) return;        // no Zstandard entry in the batch
+    __shared__ ZfShared sh;
+    zstd_fse_rows<false>(sh, src, desc, list, counters, arena, state, nullptr);
+}
+__global__ __launch_bounds__(64, 3) void k_zstd_fse_blocks(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
+                                                        const u32* __restrict__ list, u32* __restrict__ counters,
+                                                        u64* __restrict__ arena, u32* __restrict__ state, u32* __restrict__ rep_out)
+{
+    if (counters[ZF_COUNT_WORD] == 0) return;
+    __shared__ ZfShared sh;
+    zstd_fse_rows<true>(sh, src, desc, list, counters, arena, state, rep_out);
 }
 
 }  // namespace zpk
