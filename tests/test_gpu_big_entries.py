@@ -105,8 +105,9 @@ def test_big_entries_frame_parallel_equals_one_wave(codec):
     codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
     r2, out2 = codec.decode_batch_host(arc2, _descs(offs2, cs2, sizes[:5], res2["hash"], methods[:5]))
     st = codec.decode_stats()
-    # (the stored entry: slices need no frames; and the two LZ4 entries of >= 2 MiB, ONE frame each: block-parallel, lz4_pj.h)
-    assert (r2["status"] == 0).all() and st["frame_parallel_entries"] == 3, st
+    # (the stored entry: slices need no frames; the two LZ4 and the two Zstandard entries of >= 2 MiB, ONE frame each: block-parallel,
+    # lz4_pj.h / zstd_pj.h — here on frames of this library's own encoder: 64 KiB blocks, repeat-offset codes)
+    assert (r2["status"] == 0).all() and st["frame_parallel_entries"] == 5, st
     for i in range(5):
         assert np.array_equal(out2[i], plains[i])
     codec.set_option(OPT_ENC_SPLIT_MIN, 2 * M)
@@ -166,13 +167,14 @@ def test_one_large_zstd_frame_is_decoded_block_parallel(codec, cls, level):
         assert np.array_equal(out1[i], p) and np.array_equal(out0[i], p), i
 
 
-def test_reference_made_large_lz4_recipes_block_parallel(codec, golden_dir):
-    """The LZ4 entries of tests/golden/recipes_big.json (64 MiB text, 64 MiB records, 512 MiB text; sizes, frame checksums and content
-    hashes recorded from the compiled reference by tests/golden/make_golden_big.py) through the host read path: every one takes the
-    block-parallel path (2 and 16 chunks of 512 blocks: references that reach behind a chunk read finished output), verdict, size,
-    XXH3 and bytes are the reference's — and the 512 MiB entry comes home at more than 2 GiB/s, host pointer to host pointer."""
+@pytest.mark.parametrize("method", [METHOD_LZ4, METHOD_ZSTD])
+def test_reference_made_large_recipes_block_parallel(codec, golden_dir, method):
+    """The LZ4 and Zstandard entries of tests/golden/recipes_big.json (64 MiB text, 64 MiB records, 512 MiB text; sizes, frame checksums
+    and content hashes recorded from the compiled reference by tests/golden/make_golden_big.py) through the host read path: every one
+    takes the block-parallel path (several chunks of 512 blocks: references that reach behind a chunk read finished output), verdict,
+    size, XXH3 and bytes are the reference's — and the 512 MiB entry comes home at more than 2 GiB/s, host pointer to host pointer."""
     import json, time
-    recs = [r for r in json.load(open(os.path.join(golden_dir, "recipes_big.json"))) if r["method"] == METHOD_LZ4]
+    recs = [r for r in json.load(open(os.path.join(golden_dir, "recipes_big.json"))) if r["method"] == method]
     assert len(recs) == 3
     codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
     for r in recs:
@@ -180,7 +182,7 @@ def test_reference_made_large_lz4_recipes_block_parallel(codec, golden_dir):
         frame = np.frombuffer(dg.compress(r["method"], r["level"], plain), dtype=np.uint8)
         assert len(frame) == r["comp_size"] and dg.xxh3(frame) == r["frame_xxh3"], r["label"]
         arc, offs, cs = _image([frame])
-        d = _descs(offs, cs, [r["size"]], [r["hash"]], [(METHOD_LZ4, 0)])
+        d = _descs(offs, cs, [r["size"]], [r["hash"]], [(method, 0)])
         back = np.full(r["size"], 0xEE, dtype=np.uint8)                        # (touched now: the timed calls do not pay for its page faults)
         bp = (C.c_void_p * 1)(back.ctypes.data)
         res = np.zeros(1, dtype=zpack_amd.DECODE_RESULT)
@@ -192,13 +194,14 @@ def test_reference_made_large_lz4_recipes_block_parallel(codec, golden_dir):
             best = min(best, time.perf_counter() - t)
             assert rc == 0
             st = codec.decode_stats()
-            assert st["frame_parallel_entries"] == 1 and st["frame_parallel_frames"] == (r["size"] + 65535) // 65536, (r["label"], st)
+            blk = 65536 if method == METHOD_LZ4 else 131072
+            assert st["frame_parallel_entries"] == 1 and st["frame_parallel_frames"] == (r["size"] + blk - 1) // blk, (r["label"], st)
             assert int(res["status"][0]) == 0 and int(res["produced"][0]) == r["size"] and int(res["hash"][0]) == r["hash"], (r["label"], res)
             assert np.array_equal(back, plain), r["label"]
         if r["size"] >= 512 * M:
-            assert r["size"] / best > 2 * (1 << 30), "512 MiB LZ4 entry: %.2f GiB/s" % (r["size"] / best / (1 << 30))
+            assert r["size"] / best > 2 * (1 << 30), "512 MiB entry: %.2f GiB/s" % (r["size"] / best / (1 << 30))
         # a wrong expected hash: the reference's verdict for it (lib/zpack_read.c:467), bytes delivered all the same
-        d2 = _descs(offs, cs, [r["size"]], [r["hash"] ^ 2], [(METHOD_LZ4, 0)])
+        d2 = _descs(offs, cs, [r["size"]], [r["hash"] ^ 2], [(method, 0)])
         back[:] = 0
         rc = codec.L.zpk_codec_decode_batch_host(codec.h, arc.ctypes.data, arc.size, d2.ctypes.data, 1, bp, res.ctypes.data)
         assert rc == 0 and int(res["status"][0]) == 15 and int(res["hash"][0]) == r["hash"] and np.array_equal(back, plain), (r["label"], res)
@@ -244,6 +247,50 @@ def test_one_large_lz4_frame_damaged_gets_the_one_wave_verdict(codec):
             assert par == 1 and r1["status"][0] == 15 and np.array_equal(out1[0][:len(plain)], plain), label
         rc, out, got, hh = o.entry_decode(arc.tobytes(), int(offs[0]), csize, len(plain), eh, METHOD_LZ4, cap)
         assert rc == int(r1["status"][0]), (label, rc, r1)
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+
+
+def test_one_large_zstd_frame_damaged_gets_the_one_wave_verdict(codec):
+    """The same for one large Zstandard frame.  Its blocks carry no checksum, so a flipped byte often still decodes — to other bytes:
+    the block-parallel reader then sees a wrong XXH3 and leaves the entry, like everything irregular, to the one-wave decoder.
+    Status, hash, produced and bytes equal the one-wave path's and the oracle's for every variant."""
+    o = oracle()
+    rng = np.random.default_rng(23)
+    for cls, level in ((dg.TEXT, 3), (dg.RECORDS, 1)):
+        plain = dg.fill(cls, 92, 0, 3 * M + 777)
+        good = np.frombuffer(dg.compress(METHOD_ZSTD, level, plain), dtype=np.uint8).copy()
+        h = dg.xxh3(plain)
+        variants = []
+        for k in range(int(os.environ.get("ZPK_BIG_FUZZ_ITERS", "16"))):
+            b = good.copy(); at = int(rng.integers(0, len(b))); b[at] ^= 1 << int(rng.integers(0, 8))
+            variants.append(("flip@%d" % at, b, len(b), h, len(plain)))
+        for at in (4, 5, 6, 9, 10, 11, 12, 13):                              # frame header, first block header, first literals header
+            b = good.copy(); b[at] ^= 0x10
+            variants.append(("head@%d" % at, b, len(b), h, len(plain)))
+        variants.append(("comp_size - 5", good, len(good) - 5, h, len(plain)))
+        variants.append(("comp_size + 3", np.concatenate([good, np.zeros(8, np.uint8)]), len(good) + 3, h, len(plain)))
+        variants.append(("hash", good, len(good), h ^ 1, len(plain)))
+        variants.append(("capacity", good, len(good), h, len(plain) - 1))
+        variants.append(("intact", good, len(good), h, len(plain)))
+        for label, payload, csize, eh, cap in variants:
+            arc, offs, _ = _image([payload])
+            d = _descs(offs, [csize], [len(plain)], [eh], [(METHOD_ZSTD, level)])
+            d["dst_capacity"] = cap
+            codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+            r1, out1 = codec.decode_batch_host(arc, d)
+            par = codec.decode_stats()["frame_parallel_entries"]
+            codec.set_option(OPT_DEC_SPLIT_MIN, 0)
+            r0, out0 = codec.decode_batch_host(arc, d)
+            assert int(r1["status"][0]) == int(r0["status"][0]), (label, r1, r0)
+            if r0["status"][0] in (0, 15):
+                assert r1["hash"][0] == r0["hash"][0] and r1["produced"][0] == r0["produced"][0], label
+                assert np.array_equal(out1[0], out0[0]), label
+            if label == "intact":
+                assert par == 1 and r1["status"][0] == 0 and np.array_equal(out1[0], plain)
+            if label == "hash":
+                assert par == 0 and r1["status"][0] == 15 and np.array_equal(out1[0][:len(plain)], plain), label
+            rc, out, got, hh = o.entry_decode(arc.tobytes(), int(offs[0]), csize, len(plain), eh, METHOD_ZSTD, cap)
+            assert rc == int(r1["status"][0]), (label, rc, r1)
     codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
 
 
