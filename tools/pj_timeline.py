@@ -8,7 +8,7 @@ ev = []
 for r in k: ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].split('::')[-1][:18]))
 for r in m: ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r['Direction'].replace('MEMORY_COPY_', '')))
 ev.sort()
-idx = [i for i, e in enumerate(ev) if 'k_pj_parse' in e[2]]
+idx = [i for i, e in enumerate(ev) if 'k_pj_scan' in e[2]]
 i0 = idx[which]; j = i0
 while j > 0 and (ev[j - 1][2].startswith('COPY') or 'copyBuffer' in ev[j - 1][2]) and ev[i0][0] - ev[j - 1][0] < 20e6: j -= 1
 t0 = ev[j][0]; jumps = 0; jt = 0

@@ -1471,7 +1471,7 @@ static bool walk_lz4_single(const u8* p, u64 comp, u64 uncomp, std::vector<PjBlo
 // the one-wave decoder decides.
 extern "C++" {
 template <class InitFn>
-static int pj_finish(zpk_codec* c, const zpk_decode_desc& d, const std::vector<PjBlock>& hb, u64 gather_src_size, InitFn init, bool accept_mismatch,
+static int pj_finish(zpk_codec* c, const zpk_decode_desc& d, const std::vector<PjBlock>& hb, u64 chunk_blocks, u64 gather_src_size, InitFn init, bool accept_mismatch,
                      uint8_t* dst_ptr, zpk_decode_result& result, u8& redo)
 {
     const u64 nb = hb.size(), n = d.uncomp_size;
@@ -1480,7 +1480,8 @@ static int pj_finish(zpk_codec* c, const zpk_decode_desc& d, const std::vector<P
     u32* const S = (u32*)c->d_pj_S;
     hipError_t e;
     int rc;
-    const u64 nchunks = (nb + ZPK_PJ_CHUNK_BLOCKS - 1) / ZPK_PJ_CHUNK_BLOCKS;
+    if (chunk_blocks * ZPK_PJ_MAX_CHUNKS < nb) chunk_blocks = (nb + ZPK_PJ_MAX_CHUNKS - 1) / ZPK_PJ_MAX_CHUNKS;      // (small blocks, a very large entry: larger chunks)
+    const u64 nchunks = (nb + chunk_blocks - 1) / chunk_blocks;
     if (nchunks > ZPK_PJ_MAX_CHUNKS) return ZPK_OK;
     for (u64 k = 0; k < nchunks; k++) if (!c->pj_ev[k] && hipEventCreateWithFlags(&c->pj_ev[k], hipEventDisableTiming) != hipSuccess) { c->pj_ev[k] = nullptr; return ZPK_OK; }
     if (!c->s_dn && hipStreamCreateWithFlags(&c->s_dn, hipStreamNonBlocking) != hipSuccess) { c->s_dn = nullptr; return ZPK_OK; }
@@ -1504,7 +1505,7 @@ static int pj_finish(zpk_codec* c, const zpk_decode_desc& d, const std::vector<P
     // have been ENQUEUED (their events recorded).  The bytes are the entry's whatever the verdict (lib/zpack_read.c:466-468 leaves
     // them); if the path turns out not to have been regular the one-wave decoder overwrites them. ----
     std::vector<u64> chunk_hi(nchunks);
-    for (u64 k = 0; k < nchunks; k++) { const u64 b1 = (k + 1) * ZPK_PJ_CHUNK_BLOCKS; chunk_hi[k] = b1 < nb ? hb[b1].out_off : n; }
+    for (u64 k = 0; k < nchunks; k++) { const u64 b1 = (k + 1) * chunk_blocks; chunk_hi[k] = b1 < nb ? hb[b1].out_off : n; }
     std::atomic<u64> enqueued{0};
     std::atomic<int> give_up{0};
     int dn_rc = ZPK_OK; hipError_t dn_e = hipSuccess;
@@ -1531,7 +1532,7 @@ static int pj_finish(zpk_codec* c, const zpk_decode_desc& d, const std::vector<P
     bool launch_failed = false;
     u64 g_lo = 0;
     for (u64 k = 0; k < nchunks; k++) {
-        const u32 b0 = (u32)(k * ZPK_PJ_CHUNK_BLOCKS), b1 = (u32)(b0 + ZPK_PJ_CHUNK_BLOCKS < nb ? b0 + ZPK_PJ_CHUNK_BLOCKS : nb);
+        const u32 b0 = (u32)(k * chunk_blocks), b1 = (u32)(b0 + chunk_blocks < nb ? b0 + chunk_blocks : nb);
         const u64 lo = hb[b0].out_off, hi = chunk_hi[k];
         const u32 grid = (u32)((hi - (lo & ~3ull) + 1023) / 1024), jgrid = (u32)((hi - lo + 1023) / 1024);
         (void)hipMemsetAsync(c->d_pj_flags + PJ_ROUND0, 0, PJ_MAX_ROUNDS * 4, st);
@@ -1610,7 +1611,7 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
     auto init = [&](u32 b0, u32 b1, hipStream_t s2) {
         hipLaunchKernelGGL(k_pj_init, dim3(b1 - b0), dim3(256), 0, s2, (const PjBlock*)B, b0, (u32)nb, (const u64*)c->d_pj_recs, (const u32*)c->d_pj_masks, S, n, c->d_pj_flags, independent);
     };
-    return pj_finish(c, d, hb, d.comp_size, init, true, dst_ptr, result, redo);
+    return pj_finish(c, d, hb, ZPK_PJ_CHUNK_BLOCKS, d.comp_size, init, true, dst_ptr, result, redo);
 }
 
 // ONE Zstandard frame as ZSTD_compressCCtx writes it (lib/zpack_write.c:179): no dictionary, no checksum, its content size (if stated) the
@@ -1754,7 +1755,7 @@ static int decode_big_zstd_single(zpk_codec* c, const u8* archive, const zpk_dec
         hipLaunchKernelGGL(k_zpj_init, dim3(b1 - b0), dim3(256), 0, s2, (const ZpjBlock*)ZB, (const PjBlock*)B, b0, (u32)nb, (const u64*)c->d_pj_recs, (const u64*)c->d_zpj_pos,
                            (const u32*)c->d_pj_masks, S, n, c->d_pj_flags);
     };
-    return pj_finish(c, d, hb, arena_off + lit_total, init, false, dst_ptr, result, redo);
+    return pj_finish(c, d, hb, ZPK_PJ_CHUNK_BLOCKS * PJ_BLOCK / ZPJ_BLOCK, arena_off + lit_total, init, false, dst_ptr, result, redo);
 }
 
 // the frames of entries [g0, g1) of `be` as one device batch; redo[k] = 1: entry k takes the serial path after all

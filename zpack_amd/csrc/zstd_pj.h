@@ -115,28 +115,44 @@ __global__ __launch_bounds__(64, ZSTD_EXEC_WAVES_FOR_CALLEES) void k_zpj_lit(u8*
     if (!ok && lane == 0) atomicOr(&flags[PJ_ERR], 32u);
 }
 
-// one thread: the repeat offsets at every block's start (RFC 8878 3.1.1.5: 1, 4, 8 at the frame's start; Raw and RLE blocks and blocks
-// without sequences pass them on); a block the sequence stage did not finish makes the entry irregular
-__global__ void k_zpj_reps(ZpjBlock* __restrict__ blocks, u32 nblocks, const u32* __restrict__ state, const u32* __restrict__ rep_out, u32* __restrict__ flags)
+// one wave: the repeat offsets at every block's start (RFC 8878 3.1.1.5: 1, 4, 8 at the frame's start; Raw and RLE blocks and blocks
+// without sequences pass them on); a block the sequence stage did not finish makes the entry irregular.  64 blocks are loaded at a
+// time, one per lane; the walk over them is a scalar loop over the lanes (a thread that loaded block after block took 1 ms for
+// 2 048 blocks: four dependent loads each).
+__global__ __launch_bounds__(64) void k_zpj_reps(ZpjBlock* __restrict__ blocks, u32 nblocks, const u32* __restrict__ state, const u32* __restrict__ rep_out, u32* __restrict__ flags)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u32 cur[3] = {1u, 4u, 8u};
+    if (blockIdx.x != 0) return;
+    const int lane = lane_id();
+    u32 c0 = 1u, c1 = 4u, c2 = 8u;                               // (uniform)
     u32 err = 0;
-    for (u32 b = 0; b < nblocks; b++) {
-        blocks[b].rep_in[0] = cur[0]; blocks[b].rep_in[1] = cur[1]; blocks[b].rep_in[2] = cur[2];
-        if (blocks[b].type != 2 || blocks[b].nseq == 0) continue;
-        if (state[b] != 1u) { err |= 64u; continue; }
-        u32 nxt[3];
-        for (int j = 0; j < 3; j++) {
-            const u32 v = rep_out[3u * b + (u32)j];
-            if (v >> ZF_SYM_SHIFT) {
-                const u32 k = (v >> ZF_SYM_SHIFT) - 1u, dec = ((1u << ZF_SYM_SHIFT) - 1u) - (v & ((1u << ZF_SYM_SHIFT) - 1u));
-                if (k > 2u || dec >= cur[k]) { err |= 128u; nxt[j] = 1u; } else nxt[j] = cur[k] - dec;
-            } else nxt[j] = v;
+    for (u32 base = 0; base < nblocks; base += WAVE) {
+        const u32 b = base + (u32)lane;
+        const bool in = b < nblocks;
+        const bool has = in && blocks[b].type == 2 && blocks[b].nseq != 0;
+        const u32 st = has ? state[b] : 1u;
+        const u32 o0 = has ? rep_out[3u * b] : 0u, o1 = has ? rep_out[3u * b + 1u] : 0u, o2 = has ? rep_out[3u * b + 2u] : 0u;
+        const u64 hm = __ballot(has);
+        if (__ballot(has && st != 1u) != 0) err |= 64u;
+        u32 i0 = 0, i1 = 0, i2 = 0;                              // this lane's block: the history at its start
+        const int cnt = (int)(nblocks - base < WAVE ? nblocks - base : WAVE);
+        for (int i = 0; i < cnt; i++) {
+            if (lane == i) { i0 = c0; i1 = c1; i2 = c2; }
+            if (!((hm >> i) & 1)) continue;
+            const u32 v[3] = { (u32)__builtin_amdgcn_readlane((int)o0, i), (u32)__builtin_amdgcn_readlane((int)o1, i), (u32)__builtin_amdgcn_readlane((int)o2, i) };
+            u32 nx[3];
+            #pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (v[j] >> ZF_SYM_SHIFT) {
+                    const u32 k = (v[j] >> ZF_SYM_SHIFT) - 1u, dec = ((1u << ZF_SYM_SHIFT) - 1u) - (v[j] & ((1u << ZF_SYM_SHIFT) - 1u));
+                    const u32 r = k == 0 ? c0 : (k == 1 ? c1 : c2);
+                    if (k > 2u || dec >= r) { err |= 128u; nx[j] = 1u; } else nx[j] = r - dec;
+                } else nx[j] = v[j];
+            }
+            c0 = nx[0]; c1 = nx[1]; c2 = nx[2];
         }
-        cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+        if (in) { blocks[b].rep_in[0] = i0; blocks[b].rep_in[1] = i1; blocks[b].rep_in[2] = i2; }
     }
-    if (err) atomicOr(&flags[PJ_ERR], err);
+    if (err && lane == 0) atomicOr(&flags[PJ_ERR], err);
 }
 
 struct alignas(16) ZpjPosShared { u32 mask[ZPJ_BLOCK / 32]; u32 wsum[2][4]; };
@@ -231,28 +247,41 @@ __global__ __launch_bounds__(256) void k_zpj_init(const ZpjBlock* __restrict__ b
     const u32 nrec = pj[b].nrec;
     const bool lit_rle = B.lit_type == 1;
     bool bad = false;
-    for (u32 p = tid; p < out_size; p += 256) {
-        const u32 w = p >> 5;
-        const u32 rank = pre[w] + (u32)__popc(m[w] & (0xFFFFFFFFu >> (31u - (p & 31u))));      // sequences starting at or before p
-        if (rank == 0 || rank > nrec) { bad = true; continue; }
-        const u32 idx = rank - 1;
-        const u64 at = P[idx];
-        const u32 o = (u32)at, lp = (u32)(at >> 32);
-        const u32 rel = p - o;
-        u32 ll, off;
-        if (idx < B.nseq) { const u64 v = R[idx]; off = (u32)v & ((1u << ZF_SEQ_OFF_BITS) - 1u); ll = (u32)(v >> (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS)); }
-        else { ll = out_size - o; off = 0; }                     // the trailing literals
-        if (rel < ll) out[p] = PJ_LIT | (B.lit_ref + (lit_rle ? 0u : lp + rel));
-        else {
-            if (off >> ZF_SYM_SHIFT) {                           // inherited: the block's starting history, counted down
-                const u32 k = (off >> ZF_SYM_SHIFT) - 1u, dec = ((1u << ZF_SYM_SHIFT) - 1u) - (off & ((1u << ZF_SYM_SHIFT) - 1u));
-                const u32 r = k == 0 ? B.rep_in[0] : (k == 1 ? B.rep_in[1] : B.rep_in[2]);
-                if (k > 2u || dec >= r) { bad = true; continue; }
-                off = r - dec;
+    // four positions per trip: their table reads are in flight together (one at a time the loop waited ~1 us per position)
+    for (u32 p0 = tid; p0 < out_size; p0 += 1024) {
+        u32 idx[4]; u64 at[4], rec[4]; bool in[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 p = p0 + 256u * (u32)k;
+            in[k] = p < out_size;
+            const u32 w = (in[k] ? p : 0u) >> 5;
+            const u32 rank = pre[w] + (u32)__popc(m[w] & (0xFFFFFFFFu >> (31u - (p & 31u))));      // sequences starting at or before p
+            if (in[k] && (rank == 0 || rank > nrec)) { bad = true; in[k] = false; }
+            idx[k] = in[k] ? rank - 1 : 0u;
+        }
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { at[k] = P[idx[k]]; rec[k] = idx[k] < B.nseq ? R[idx[k]] : 0ull; }
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!in[k]) continue;
+            const u32 p = p0 + 256u * (u32)k;
+            const u32 o = (u32)at[k], lp = (u32)(at[k] >> 32);
+            const u32 rel = p - o;
+            u32 ll, off;
+            if (idx[k] < B.nseq) { off = (u32)rec[k] & ((1u << ZF_SEQ_OFF_BITS) - 1u); ll = (u32)(rec[k] >> (ZF_SEQ_OFF_BITS + ZF_SEQ_ML_BITS)); }
+            else { ll = out_size - o; off = 0; }                 // the trailing literals
+            if (rel < ll) out[p] = PJ_LIT | (B.lit_ref + (lit_rle ? 0u : lp + rel));
+            else {
+                if (off >> ZF_SYM_SHIFT) {                       // inherited: the block's starting history, counted down
+                    const u32 kk = (off >> ZF_SYM_SHIFT) - 1u, dec = ((1u << ZF_SYM_SHIFT) - 1u) - (off & ((1u << ZF_SYM_SHIFT) - 1u));
+                    const u32 r = kk == 0 ? B.rep_in[0] : (kk == 1 ? B.rep_in[1] : B.rep_in[2]);
+                    if (kk > 2u || dec >= r) { bad = true; continue; }
+                    off = r - dec;
+                }
+                const u64 here = (u64)out_off + p;               // bytes of the frame in front of this one
+                if (off == 0 || off > here) { bad = true; continue; }
+                out[p] = (u32)(here - off);
             }
-            const u64 here = (u64)out_off + p;                   // bytes of the frame in front of this one
-            if (off == 0 || off > here) { bad = true; continue; }
-            out[p] = (u32)(here - off);
         }
     }
     if (bad) atomicOr(&flags[PJ_ERR], 4u);
