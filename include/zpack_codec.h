@@ -218,9 +218,20 @@ int  zpk_dstream_step(zpk_dstream* s, uint32_t method, uint64_t entry_comp_size,
                       uint64_t entry_hash, const uint8_t* in, size_t in_size, size_t* consumed,
                       uint8_t* out, size_t out_cap, size_t* produced, int* done);
 
+/* Bounded memory (round 5): a large entry that is one plain LZ4 frame is decoded in block-parallel steps and the stream holds only a window
+ * of it.  zpk_dstream_wants_input() == 0: the stream has output waiting and takes no input — call zpk_dstream_step with in_size 0.
+ * zpk_dstream_step may answer ZPK_DS_RESTART (not a zpack_result): the entry is not what the steps can decide; feed the entry's bytes
+ * [0, bytes given so far) again through zpk_dstream_replay (first = 1 with the first piece) and go on with zpk_dstream_step: the
+ * stream continues in its windowless form, where the verdicts are; nothing is handed out twice. */
+#define ZPK_DS_RESTART 1001
+int  zpk_dstream_wants_input(const zpk_dstream* s);
+int  zpk_dstream_replay(zpk_dstream* s, uint32_t method, uint64_t entry_comp_size, uint64_t entry_uncomp_size, uint64_t entry_hash,
+                        const uint8_t* in, size_t in_size, int first);
+
 /* diagnostics: device decode steps launched / calls served since the stream's last reset (small chunks are gathered on the host: at
  * most one launch per 256 KiB of input) */
 void zpk_dstream_counters(const zpk_dstream* s, uint64_t* launches, uint64_t* calls);
+uint64_t zpk_dstream_device_bytes(const zpk_dstream* s);   /* diagnostics: device memory the stream holds right now */
 
 typedef struct zpk_cstream zpk_cstream;
 int  zpk_cstream_create(zpk_codec* c, zpk_cstream** out);

@@ -84,10 +84,11 @@ __global__ __launch_bounds__(64) void k_pj_parse(const u8* __restrict__ src, u64
 }
 
 // output offsets of the blocks (one wave; a frame of 1 GiB has 16 384 blocks)
-__global__ __launch_bounds__(64) void k_pj_scan(PjBlock* __restrict__ blocks, u32 nblocks, u32* __restrict__ flags)
+// (first: the output offset of block 0 — a stream's step has the bytes of its history in front, zpk_stream.inc)
+__global__ __launch_bounds__(64) void k_pj_scan(PjBlock* __restrict__ blocks, u32 nblocks, u32* __restrict__ flags, u32 first = 0)
 {
     const int lane = lane_id();
-    u64 base = 0;
+    u64 base = first;
     for (u32 b0 = 0; b0 < nblocks; b0 += WAVE) {
         const u32 b = b0 + (u32)lane;
         const u32 sz = b < nblocks ? blocks[b].out_size : 0u;

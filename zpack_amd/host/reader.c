@@ -434,6 +434,28 @@ int zpack_read_files_packed(zpack_reader* reader, zpack_file_entry* const* entri
     return rc;
 }
 
+static int zi_stream_replay(zpack_reader* reader, const zpack_file_entry* entry, zpk_dstream* d, zpack_u64 upto)
+{
+    const size_t piece = (size_t)1 << 20;
+    zpack_u8* tmp = (zpack_u8*)malloc(piece);
+    if (!tmp) return ZPACK_ERROR_MALLOC_FAILED;
+    int rc = ZPACK_OK, first = 1;
+    for (zpack_u64 off = 0; (off < upto || first) && rc == ZPACK_OK; ) {
+        const size_t n = (size_t)(upto - off < piece ? upto - off : piece);
+        const zpack_u64 at = entry->offset + off;
+        if (n) {
+            if (reader->file) rc = read_at(reader->file, at, tmp, n);
+            else if (reader->buffer) memcpy(tmp, reader->buffer + at, n);
+            else rc = ZPACK_ERROR_ARCHIVE_NOT_LOADED;
+        }
+        if (rc == ZPACK_OK) rc = zpk_dstream_replay(d, entry->comp_method, entry->comp_size, entry->uncomp_size, entry->hash, tmp, n, first);
+        first = 0; off += n;
+        if (n == 0) break;
+    }
+    free(tmp);
+    return rc;
+}
+
 /* streaming read (lib/zpack_read.c:515-640): the same observable protocol — the library pulls the
  * compressed bytes into the caller's input window, output arrives in avail_out pieces, read_back != 0
  * means "call again" — served by aggregating the entry and decoding it in one device batch. */
@@ -457,7 +479,8 @@ int zpack_read_file_stream(zpack_reader* reader, zpack_file_entry* entry, zpack_
         src = stream->next_in;
         stream->read_back = 0;
     }
-    if (stream->total_in < entry->comp_size) {
+    /* (a stream that decodes in bounded memory takes no input while output is waiting: nothing is pulled then) */
+    if (stream->total_in < entry->comp_size && zpk_dstream_wants_input(st->d)) {
         size_t got = 0;
         int rc = zpack_read_raw_file_stream(reader, entry, stream, &got);
         if (rc) return rc;
@@ -467,6 +490,14 @@ int zpack_read_file_stream(zpack_reader* reader, zpack_file_entry* entry, zpack_
     int done = 0;
     int rc = zpk_dstream_step(st->d, entry->comp_method, entry->comp_size, entry->uncomp_size, entry->hash,
                               src, have, &consumed, stream->next_out, stream->avail_out, &produced, &done);
+    if (rc == ZPK_DS_RESTART) {
+        /* not an entry the bounded steps can decide: the bytes read so far go through the stream again (1 MiB at a time out of
+         * the archive), it continues in its windowless form — where every verdict is — and hands out nothing twice */
+        rc = zi_stream_replay(reader, entry, st->d, stream->total_in);
+        if (rc == ZPACK_OK)
+            rc = zpk_dstream_step(st->d, entry->comp_method, entry->comp_size, entry->uncomp_size, entry->hash,
+                                  src, 0, &consumed, stream->next_out, stream->avail_out, &produced, &done);
+    }
     stream->next_out += produced; stream->avail_out -= produced; stream->total_out += produced;
     if (rc != ZPACK_OK && rc != ZPACK_ERROR_FILE_HASH_MISMATCH) { reader->last_return = (size_t)-1; return rc; }
     if (stream->total_in == entry->comp_size && !done) stream->read_back = 1;   /* output still pending: not DONE yet */
