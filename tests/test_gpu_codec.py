@@ -528,6 +528,52 @@ def _stream_decode(codec, frame, method, uncomp_size, want_hash, chunk, out_chun
     return status, bytes(out), first
 
 
+@pytest.mark.parametrize("level", [1, 3])
+def test_stream_large_zstd_entry_goes_in_bounded_block_parallel_steps(codec, level):
+    """The same for one plain Zstandard frame (lib/zpack_write.c:179): steps of up to 64 blocks behind the frame's window; the repeat
+    offsets, the running XXH3 and the last block with a Huffman tree travel from step to step."""
+    size = 40 << 20
+    tile = np.concatenate([dg.fill(k % 2, 43, k, 1 << 20) for k in range(8)])
+    plain = np.ascontiguousarray(np.resize(tile, size))
+    frame = dg.compress(dg.ZSTD, level, plain)
+    h = dg.xxh3(plain)
+    st, out, first = _stream_decode(codec, frame, dg.ZSTD, size, h, 131072, 1 << 20)
+    stats = _stream_decode.stats
+    assert st == 0 and out == plain.tobytes(), (st, stats)
+    assert stats["restarts"] == 0 and first is not None and first <= 4 * 131072, (stats, first)
+    assert stats["device_peak"] < (64 << 20) and 4 <= stats["steps"] <= 64, stats
+    st, out, _ = _stream_decode(codec, frame, dg.ZSTD, size, h ^ 4, 131072, 1 << 20)
+    assert st == 15 and out == plain.tobytes() and _stream_decode.stats["restarts"] == 0
+    for cls in (dg.TEXT, dg.RUNS, dg.RANDOM):                   # Treeless chains, RLE / raw blocks
+        p1 = dg.fill(cls, 44, 0, 6 << 20)
+        f1 = dg.compress(dg.ZSTD, level, p1)
+        st, out, _ = _stream_decode(codec, f1, dg.ZSTD, len(p1), dg.xxh3(p1), 100000, 300000)
+        assert st == 0 and out == p1.tobytes(), (cls, st, _stream_decode.stats)
+    # ---- what the steps do not decide ----
+    small = 6 << 20
+    p2 = plain[:small]
+    f2 = bytearray(dg.compress(dg.ZSTD, level, p2))
+    h2 = dg.xxh3(p2)
+    rng = np.random.default_rng(10)
+    variants = [("bytes behind the last block", bytes(f2) + b"\0\0\0", small, h2),
+                ("two frames", bytes(f2) + bytes(f2), 2 * small, dg.xxh3(np.concatenate([p2, p2]))),
+                ("truncated", bytes(f2[:-9]), small, h2),
+                ("claims less", bytes(f2), small - 1000, h2)]
+    for k in range(8):
+        b = bytearray(f2); at = int(rng.integers(len(b) // 3, len(b))); b[at] ^= 1 << int(rng.integers(0, 8))
+        variants.append(("flip@%d" % at, bytes(b), small, h2))
+    for label, payload, usize, hh in variants:
+        arc = np.concatenate([np.zeros(10, np.uint8), np.frombuffer(payload, dtype=np.uint8), np.zeros(64, np.uint8)])
+        d = np.zeros(1, dtype=zpack_amd.DECODE_DESC)
+        d["src_offset"] = 10; d["comp_size"] = len(payload); d["uncomp_size"] = usize; d["expect_hash"] = hh; d["dst_capacity"] = usize; d["method"] = dg.ZSTD
+        r, o1 = codec.decode_batch_host(arc, d)
+        st, out, _ = _stream_decode(codec, payload, dg.ZSTD, usize, hh, 131072, 1 << 20)
+        one = int(r["status"][0])
+        assert st == one, (label, st, one, _stream_decode.stats)
+        if one in (0, 15):
+            assert out == o1[0][:usize].tobytes(), label
+
+
 def test_stream_large_lz4_entry_goes_in_bounded_block_parallel_steps(codec):
     """A large entry that is one plain LZ4 frame (what the reference writer produces, lib/zpack_write.c:204-210) streams in steps of up
     to 64 blocks decoded side by side; the stream holds a window of the entry, not the entry: ~40 MiB of device memory for 48 MiB of

@@ -332,9 +332,16 @@ def _rss_bytes():
         return int(fh.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
 
 
-def _stream_entry(Z, r, i, in_window, out_window, sink):
+def _device_used():
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    return total - free
+
+
+def _stream_entry(Z, r, i, in_window, out_window, sink, dev=None):
     """zpack_read_file_stream with the caller's loop of tests/read_archive.c:38-82 / programs/commands.c:326-400.
-    -> (rc of the last call, total_in at the first output byte, peak RSS growth while streaming)"""
+    -> (rc of the last call, total_in at the first output byte, peak RSS growth while streaming); dev (a dict): its "peak" becomes the
+    growth of the device's used memory while streaming (sampled every 16 calls)"""
     st = Stream()
     assert Z.lib.zpack_init_stream(C.byref(st)) == 0
     in_buf = (C.c_uint8 * in_window)()
@@ -343,7 +350,10 @@ def _stream_entry(Z, r, i, in_window, out_window, sink):
     Z.lib.zpack_reset_stream(C.byref(st))
     rss0, rss_peak, first_out_in, pos, rc = _rss_bytes(), 0, None, 0, 0
     idle = 0
-    for _ in range(10_000_000):
+    dev0 = _device_used() if dev is not None else 0
+    for it in range(10_000_000):
+        if dev is not None and it % 16 == 8:
+            dev["peak"] = max(dev.get("peak", 0), _device_used() - dev0)
         before_in = st.total_in
         if st.read_back:
             tail = C.string_at(C.addressof(st.next_in.contents) - st.read_back, st.read_back)
@@ -389,10 +399,13 @@ def test_stream_read_is_bounded_and_incremental(Z, golden_dir, label):
     sink = np.full(size, 0xEE, dtype=np.uint8)                                             # (touched now: its pages are not growth later)
     rc, r, keep = Z.open_memory(arc)
     assert rc == 0
-    rc, first_out_in, rss_peak, got = _stream_entry(Z, r, 0, 131075, 1 << 20, sink)
+    dev = {}
+    rc, first_out_in, rss_peak, got = _stream_entry(Z, r, 0, 131075, 1 << 20, sink, dev)
     Z.lib.zpack_close_reader(C.byref(r))
     assert rc == 0 and got == size and np.array_equal(sink, plain)
     assert first_out_in is not None and first_out_in <= 4 * 131075, first_out_in          # output after the first block(s), not after the last input byte
+    if not label.startswith("none"):                                                      # (round 5) bounded on the DEVICE too: a window of the entry, in block-parallel steps
+        assert dev["peak"] < (64 << 20), dev
     assert first_out_in < len(frame) // 8
     if len(frame) >= (128 << 20):                                                         # (smaller entries drown in allocator noise)
         assert rss_peak < (64 << 20), (rss_peak, len(frame))                              # no host copy of the compressed entry, let alone the output

@@ -1614,6 +1614,81 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
     return pj_finish(c, d, hb, ZPK_PJ_CHUNK_BLOCKS, d.comp_size, init, true, dst_ptr, result, redo);
 }
 
+// One block of a Zstandard frame at p (avail bytes follow): 1 = parsed into B (hdr_off = at; sizes, literals and sequence headers; nothing
+// about trees or slots), 0 = the bytes end inside it, -1 = not a block this path takes (reserved type, Repeat_Mode table, sizes that
+// disagree).  *last = its Last_Block bit, *total = 3 + the bytes of its body.
+static int zpj_parse_block(const u8* p, u64 avail, u64 at, ZpjBlock& B, u32* last, u64* total)
+{
+    if (avail < 3) return 0;
+    const u32 bh = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16);
+    const u32 bt = (bh >> 1) & 3, bs = bh >> 3;
+    *last = bh & 1;
+    memset(&B, 0, sizeof(B));
+    B.hdr_off = (u32)at; B.type = bt; B.size = bs; B.tree_src = ZPJ_NONE;
+    if (bt == 3 || bs > ZPJ_BLOCK || at > 0x7FFFFF00ull) return -1;
+    const u64 body = bt == 1 ? 1 : bs;
+    *total = 3 + body;
+    if (avail - 3 < body) return 0;
+    if (bt != 2) return 1;
+    const u8* const b = p + 3;
+    if (bs < 3) return -1;
+    const u32 b0 = b[0], lt = b0 & 3, fmt = (b0 >> 2) & 3;
+    u32 hl, regen, csize;
+    if (lt < 2) {
+        if ((fmt & 1) == 0) { hl = 1; regen = b0 >> 3; }
+        else if (fmt == 1) { hl = 2; regen = (b0 >> 4) | ((u32)b[1] << 4); }
+        else { hl = 3; regen = (b0 >> 4) | ((u32)b[1] << 4) | ((u32)b[2] << 12); }
+        csize = lt == 0 ? regen : 1u;
+    } else {
+        if (bs < 5) return -1;
+        const u64 v = hrd32(b);
+        if (fmt < 2) { hl = 3; regen = (u32)(v >> 4) & 0x3FF; csize = (u32)(v >> 14) & 0x3FF; }
+        else if (fmt == 2) { hl = 4; regen = (u32)(v >> 4) & 0x3FFF; csize = (u32)(v >> 18); }
+        else { hl = 5; regen = (u32)(v >> 4) & 0x3FFFF; csize = (u32)(v >> 22) | ((u32)b[4] << 10); }
+    }
+    if (regen > ZPJ_BLOCK || (u64)hl + csize > bs) return -1;
+    B.lit_type = lt; B.lit_size = regen; B.lit_used = hl + csize;
+    if (lt < 2) B.lit_ref = (u32)(at + 3 + hl);
+    u64 o = B.lit_used;
+    if (bs - o < 1) return -1;
+    u64 nseq = b[o];
+    if (nseq == 0) { if (bs - o != 1) return -1; }
+    else {
+        if (nseq < 128) o += 1;
+        else if (nseq < 255) { if (bs - o < 2) return -1; nseq = ((nseq - 128) << 8) + b[o + 1]; o += 2; }
+        else { if (bs - o < 3) return -1; nseq = (u64)b[o + 1] + ((u64)b[o + 2] << 8) + 0x7F00; o += 3; }
+        if (bs - o < 1) return -1;
+        const u32 modes = b[o];
+        if ((modes & 3) || ((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3) return -1;
+    }
+    B.nseq = (u32)nseq;
+    return 1;
+}
+
+// The header of a Zstandard frame as ZSTD_compressCCtx writes it (lib/zpack_write.c:179): no dictionary, no checksum, a window of at
+// most 2^max_wlog bytes.  -> its size (0: the bytes end inside it, -1: not this path's); *window = Window_Size, *fcs = content size or ~0.
+static int zpj_parse_frame_header(const u8* p, u64 avail, u32 max_wlog, u64* window, u64* fcs)
+{
+    if (avail < 6) return 0;
+    if (hrd32(p) != 0xFD2FB528u) return -1;
+    u64 q = 4;
+    const u32 fhd = p[q++];
+    const u32 fcs_flag = fhd >> 6, single = (fhd >> 5) & 1;
+    if (fhd & 0x0F) return -1;                                      // reserved bit, content checksum, dictionary: the one-wave decoder's
+    *window = 0;
+    if (!single) {
+        const u32 wdesc = p[q++], wlog = 10 + (wdesc >> 3);
+        if (wlog > max_wlog) return -1;
+        *window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wdesc & 7);
+    }
+    const u32 fn = fcs_flag == 0 ? (single ? 1u : 0u) : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+    if (avail - q < fn) return 0;
+    *fcs = ~0ull;
+    if (fn) { u64 v = 0; for (u32 i = 0; i < fn; i++) v |= (u64)p[q + i] << (8 * i); if (fn == 2) v += 256; *fcs = v; q += fn; }
+    if (single) *window = *fcs;
+    return (int)q;
+}
+
 // ONE Zstandard frame as ZSTD_compressCCtx writes it (lib/zpack_write.c:179): no dictionary, no checksum, its content size (if stated) the
 // entry's, a window of at most 128 MiB, no Repeat_Mode table, every Treeless block behind a block with a tree, >= ZPK_PJ_MIN_BLOCKS
 // blocks, nothing behind the last block -> the block table of zstd_pj.h.  slots = sequence slots (a block owns nseq + 1), lit_total =
@@ -1621,66 +1696,23 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
 static bool walk_zstd_single(const u8* p, u64 comp, u64 uncomp, std::vector<ZpjBlock>& blocks, u64& slots, u64& lit_total)
 {
     blocks.clear(); slots = 0; lit_total = 0;
-    if (comp < 9 || hrd32(p) != 0xFD2FB528u) return false;
-    u64 q = 4;
-    const u32 fhd = p[q++];
-    const u32 fcs_flag = fhd >> 6, single = (fhd >> 5) & 1;
-    if (fhd & 0x0F) return false;                                   // reserved bit, content checksum, dictionary: the one-wave decoder's
-    if (!single) { const u32 wdesc = p[q++]; if (10 + (wdesc >> 3) > 27) return false; }
-    const u32 fn = fcs_flag == 0 ? (single ? 1u : 0u) : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
-    if (comp - q < fn) return false;
-    if (fn) { u64 fcs = 0; for (u32 i = 0; i < fn; i++) fcs |= (u64)p[q + i] << (8 * i); if (fn == 2) fcs += 256; if (fcs != uncomp) return false; q += fn; }
+    u64 window = 0, fcs = ~0ull;
+    const int hdr = zpj_parse_frame_header(p, comp, 27, &window, &fcs);
+    if (hdr <= 0 || (fcs != ~0ull && fcs != uncomp)) return false;
+    u64 q = (u64)hdr;
     u32 tree = ZPJ_NONE;
     for (;;) {
-        if (comp - q < 3) return false;
-        const u32 bh = (u32)p[q] | ((u32)p[q + 1] << 8) | ((u32)p[q + 2] << 16);
-        const u32 last = bh & 1, bt = (bh >> 1) & 3, bs = bh >> 3;
-        ZpjBlock B; memset(&B, 0, sizeof(B));
-        B.hdr_off = (u32)q; B.type = bt; B.size = bs; B.tree_src = ZPJ_NONE;
-        if (bt == 3 || bs > ZPJ_BLOCK || q > 0x7FFFFF00ull) return false;
-        const u64 body = bt == 1 ? 1 : bs;
-        if (comp - q - 3 < body) return false;
-        if (bt == 2) {
-            const u8* const b = p + q + 3;
-            if (bs < 3) return false;
-            const u32 b0 = b[0], lt = b0 & 3, fmt = (b0 >> 2) & 3;
-            u32 hl, regen, csize;
-            if (lt < 2) {
-                if ((fmt & 1) == 0) { hl = 1; regen = b0 >> 3; }
-                else if (fmt == 1) { hl = 2; regen = (b0 >> 4) | ((u32)b[1] << 4); }
-                else { hl = 3; regen = (b0 >> 4) | ((u32)b[1] << 4) | ((u32)b[2] << 12); }
-                csize = lt == 0 ? regen : 1u;
-            } else {
-                if (bs < 5) return false;
-                const u64 v = hrd32(b);
-                if (fmt < 2) { hl = 3; regen = (u32)(v >> 4) & 0x3FF; csize = (u32)(v >> 14) & 0x3FF; }
-                else if (fmt == 2) { hl = 4; regen = (u32)(v >> 4) & 0x3FFF; csize = (u32)(v >> 18); }
-                else { hl = 5; regen = (u32)(v >> 4) & 0x3FFFF; csize = (u32)(v >> 22) | ((u32)b[4] << 10); }
-            }
-            if (regen > ZPJ_BLOCK || (u64)hl + csize > bs) return false;
-            B.lit_type = lt; B.lit_size = regen; B.lit_used = hl + csize;
-            if (lt == 2) tree = (u32)blocks.size();
-            if (lt == 3) { if (tree == ZPJ_NONE) return false; B.tree_src = tree; }
-            if (lt < 2) B.lit_ref = (u32)(q + 3 + hl);
-            else { B.lit_base = (u32)lit_total; lit_total += ((u64)regen + 15) / 16 * 16 + 64; }
-            u64 o = B.lit_used;
-            if (bs - o < 1) return false;
-            u64 nseq = b[o];
-            if (nseq == 0) { if (bs - o != 1) return false; }
-            else {
-                if (nseq < 128) o += 1;
-                else if (nseq < 255) { if (bs - o < 2) return false; nseq = ((nseq - 128) << 8) + b[o + 1]; o += 2; }
-                else { if (bs - o < 3) return false; nseq = (u64)b[o + 1] + ((u64)b[o + 2] << 8) + 0x7F00; o += 3; }
-                if (bs - o < 1) return false;
-                const u32 modes = b[o];
-                if ((modes & 3) || ((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3) return false;
-            }
-            B.nseq = (u32)nseq;
+        ZpjBlock B; u32 last = 0; u64 total = 0;
+        if (zpj_parse_block(p + q, comp - q, q, B, &last, &total) != 1) return false;
+        if (B.type == 2) {
+            if (B.lit_type == 2) tree = (u32)blocks.size();
+            if (B.lit_type == 3) { if (tree == ZPJ_NONE) return false; B.tree_src = tree; }
+            if (B.lit_type >= 2) { B.lit_base = (u32)lit_total; lit_total += ((u64)B.lit_size + 15) / 16 * 16 + 64; }
             B.seq_base = (u32)slots;
-            slots += nseq + 1;
+            slots += (u64)B.nseq + 1;
         }
         blocks.push_back(B);
-        q += 3 + body;
+        q += total;
         if (last) break;
         if (slots > 0x7FFFFF00ull || lit_total > 0x70000000ull) return false;
     }

@@ -29,6 +29,7 @@ namespace zpk {
 
 #define ZPJ_BLOCK (128u << 10)
 #define ZPJ_NONE 0xFFFFFFFFu
+#define ZPJ_TREE_ONLY 3u                           // ZpjBlock::type of a stream step's first table entry: a block of an earlier step, here only for its Huffman tree
 struct ZpjBlock {
     u32 hdr_off;             // offset of the 3-byte block header in the compressed entry
     u32 size;                // Block_Size (Compressed / Raw: bytes of content; RLE: the regenerated size)
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64, ZSTD_EXEC_WAVES_FOR_CALLEES) void k_zpj_lit(u8*
     bool ok = (u64)hdr + 3 + size <= src_size;
     if (ok && lt == 3) {                                         // the tree of the block this one inherits from
         const u32 t = uni(blocks[b].tree_src);
-        ok = t < b && uni(blocks[t].type) == 2 && uni(blocks[t].lit_type) == 2;
+        ok = t < b && (uni(blocks[t].type) == 2 || uni(blocks[t].type) == ZPJ_TREE_ONLY) && uni(blocks[t].lit_type) == 2;
         if (ok) {
             const u8* const tp = src + uni(blocks[t].hdr_off) + 3;
             const ZpjLitHdr th = zpj_lit_hdr(tp, uni(blocks[t].size));
@@ -119,11 +120,15 @@ __global__ __launch_bounds__(64, ZSTD_EXEC_WAVES_FOR_CALLEES) void k_zpj_lit(u8*
 // without sequences pass them on); a block the sequence stage did not finish makes the entry irregular.  64 blocks are loaded at a
 // time, one per lane; the walk over them is a scalar loop over the lanes (a thread that loaded block after block took 1 ms for
 // 2 048 blocks: four dependent loads each).
-__global__ __launch_bounds__(64) void k_zpj_reps(ZpjBlock* __restrict__ blocks, u32 nblocks, const u32* __restrict__ state, const u32* __restrict__ rep_out, u32* __restrict__ flags)
+// (r0, r1, r2: the history in front of block 0 — 1, 4, 8 at a frame's start; a stream's step continues with what the step before left
+// in flags[ZPJ_REPS ..])
+#define ZPJ_REPS 36
+__global__ __launch_bounds__(64) void k_zpj_reps(ZpjBlock* __restrict__ blocks, u32 nblocks, const u32* __restrict__ state, const u32* __restrict__ rep_out, u32* __restrict__ flags,
+                                                 u32 r0 = 1u, u32 r1 = 4u, u32 r2 = 8u)
 {
     if (blockIdx.x != 0) return;
     const int lane = lane_id();
-    u32 c0 = 1u, c1 = 4u, c2 = 8u;                               // (uniform)
+    u32 c0 = r0, c1 = r1, c2 = r2;                               // (uniform)
     u32 err = 0;
     for (u32 base = 0; base < nblocks; base += WAVE) {
         const u32 b = base + (u32)lane;
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(64) void k_zpj_reps(ZpjBlock* __restrict__ blocks, 
         }
         if (in) { blocks[b].rep_in[0] = i0; blocks[b].rep_in[1] = i1; blocks[b].rep_in[2] = i2; }
     }
+    if (lane == 0) { flags[ZPJ_REPS] = c0; flags[ZPJ_REPS + 1] = c1; flags[ZPJ_REPS + 2] = c2; }
     if (err && lane == 0) atomicOr(&flags[PJ_ERR], err);
 }
 
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void k_zpj_pos(const ZpjBlock* __restrict__ bl
     if (b >= nblocks) return;
     const ZpjBlock B = blocks[b];
     if (B.type != 2) {
-        if (tid == 0) { pj[b].out_size = B.size; pj[b].nrec = 0; }
+        if (tid == 0) { pj[b].out_size = B.type == ZPJ_TREE_ONLY ? 0u : B.size; pj[b].nrec = 0; }
         return;
     }
     for (u32 i = tid; i < ZPJ_BLOCK / 32; i += 256) sh.mask[i] = 0;
