@@ -8,6 +8,7 @@
 #   e: the LZ4 two-stage A/B of round 4 (one-kernel path / stage 2 over the output slot / stage 2 with the LDS window), stream rates
 #   f: soak of the streaming write / read pair (600 random sizes, chunkings and windows)
 #   g: scheduling and large entries (round 4): work lists largest first A/B (C4, C2, C3), ragged encode batch A/B, one 256 MiB entry
+#   h: round 5: one large reference-made frame through the host read path and through the streaming reader
 # Everything lands under gpurun_out/<tag>/; the PMC summaries are also copied to profiles/<tag>/ ON THE BOX so that the bench lines quote them.
 part=${1:-a}; tag=${2:-r04}
 out=gpurun_out/$tag
@@ -34,6 +35,7 @@ b)
   trace c3_zstd --workload c3_zstd_256k --steps 3 --warmup 1
   pmc2 c3 c3_zstd_256k 100000 --workload c3_zstd_256k
   timeout -k 10 900 python bench.py --workload c3_zstd_256k --steps 3 --warmup 1 > $out/${tag}_c3_zstd_bench.json 2> $out/c3.err; echo "bench c3 rc=$?"; line c3_zstd
+  trace c4_mixed --workload c4_mixed --steps 3 --warmup 1
   pmc2 c4 c4_mixed 125000 --workload c4_mixed
   timeout -k 10 900 python bench.py --workload c4_mixed --steps 3 --warmup 1 > $out/${tag}_c4_mixed_bench.json 2> $out/c4.err; echo "bench c4 rc=$?"; line c4_mixed
   timeout -k 10 600 python bench.py --gpus 4 --workload c4_mixed --entries 40000 --steps 3 --warmup 1 --no-cpu > $out/${tag}_c4_4rank_40000_one_card_rehearsal.json 2> $out/strong.err; echo "4-rank rc=$?"; cut -c1-300 $out/${tag}_c4_4rank_40000_one_card_rehearsal.json
@@ -57,6 +59,12 @@ e)
 g)
   tools/attic/r4_order.sh 2>&1 | tee $out/${tag}_order_ab.txt
   timeout -k 10 600 python3 tools/enc_ragged.py 30000 1 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_enc_ragged_order.txt
+  timeout -k 10 400 python3 tools/big_entry_rate.py 256 16 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_entry_rate.txt ;;
+h)   # round 5: ONE large frame of the reference writer through the host read path (block-parallel) and through zpack_read_file_stream (bounded steps)
+  timeout -k 10 300 python3 tools/big_frame_rate.py 256 16 lz4 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_lz4_frame_rate.txt
+  timeout -k 10 300 python3 tools/big_frame_rate.py 256 8 zstd 3 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_zstd_frame_rate.txt
+  timeout -k 10 300 python3 tools/big_frame_rate.py 256 8 zstd 1 2>&1 | grep -v amdgpu.ids | tee -a $out/${tag}_big_zstd_frame_rate.txt
+  timeout -k 10 600 python3 tools/stream_rate.py lz4_0_64m_text,lz4_0_64m_records,lz4_0_512m_text,zstd_3_64m_text,zstd_3_64m_records,zstd_3_512m_text 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_stream_read_rate.txt
   timeout -k 10 400 python3 tools/big_entry_rate.py 256 16 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_entry_rate.txt ;;
 f)
   # soak of the streaming write / read pair: random entry sizes, chunkings and windows (the suite runs 30 of these; here 600 more, other seed)
