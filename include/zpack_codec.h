@@ -142,6 +142,13 @@ int zpk_codec_decode_batch_device(zpk_codec* c, const uint8_t* src, uint64_t src
                                   uint8_t* dst, uint64_t dst_size,
                                   zpk_decode_result* results, void* stream);
 
+/* ONE entry whose compressed bytes are in DEVICE memory, decoded into device memory (d_dst + desc->dst_offset); desc and result are host
+ * memory; returns when the entry is decoded and verified.  A large entry that is one frame of the reference writer
+ * (lib/zpack_write.c:179, :204-210) is decoded block-parallel — 13-17 GiB/s instead of one wave's 0.03-0.14; anything else runs through the
+ * kernels of zpk_codec_decode_batch_device.  Same verdicts either way (what zpack_read_file would return, lib/zpack_read.c:326-471). */
+int  zpk_codec_decode_big_device(zpk_codec* c, const uint8_t* d_archive, uint64_t archive_size, const zpk_decode_desc* desc,
+                                 uint8_t* d_dst, uint64_t dst_size, zpk_decode_result* result);
+
 /* Host form: host pointers, synchronous.  Stages [min src_offset, max src_offset+comp_size) of
  * `archive` to the device, decodes, and copies each slot back to dst_ptrs[i] (desc[i].dst_offset is
  * ignored; desc[i].dst_capacity is the size of dst_ptrs[i]).  zpack_read_file is a batch of one. */

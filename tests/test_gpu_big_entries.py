@@ -294,6 +294,54 @@ def test_one_large_zstd_frame_damaged_gets_the_one_wave_verdict(codec):
     codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
 
 
+@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 3)])
+def test_large_entry_in_device_memory_is_decoded_block_parallel(codec, method, level):
+    """zpk_codec_decode_big_device: the entry's compressed bytes are on the device, the output stays on the device (GPU pipelines).  A large
+    frame of the reference writer goes block-parallel (its bytes visit the host once, for the walk over the block headers); a damaged
+    one, a small one and a stored one get exactly what zpk_codec_decode_batch_device gives them."""
+    import torch
+    dev = torch.device("cuda:0")
+    size = 24 * M + 4321
+    plain = dg.fill(dg.TEXT, 95, 0, size)
+    frame = np.frombuffer(dg.compress(method, level, plain), dtype=np.uint8)
+    h = dg.xxh3(plain)
+
+    def run(payload, usize, want_hash, meth):
+        src = torch.zeros(10 + len(payload) + 64, dtype=torch.uint8, device=dev)
+        src[10:10 + len(payload)] = torch.from_numpy(np.array(payload, dtype=np.uint8, copy=True)).to(dev)
+        dst = torch.full((256 + usize + 64,), 0xEE, dtype=torch.uint8, device=dev)
+        d = np.zeros(1, dtype=zpack_amd.DECODE_DESC)
+        d["src_offset"] = 10; d["comp_size"] = len(payload); d["uncomp_size"] = usize; d["expect_hash"] = want_hash
+        d["dst_offset"] = 256; d["dst_capacity"] = usize; d["method"] = meth
+        r = codec.decode_big_device(src, d, dst)
+        par = codec.decode_stats()["frame_parallel_entries"]
+        # the same through the batch call
+        dst2 = torch.full((256 + usize + 64,), 0xEE, dtype=torch.uint8, device=dev)
+        ddesc = torch.from_numpy(d.view(np.uint8)).to(dev)
+        dres = torch.zeros(zpack_amd.DECODE_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        codec.decode_batch_device(src, ddesc, 1, dst2, dres)
+        torch.cuda.synchronize()
+        r2 = dres.cpu().numpy().view(zpack_amd.DECODE_RESULT)[0]
+        return r, par, dst.cpu().numpy(), r2, dst2.cpu().numpy()
+
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    r, par, out, r2, out2 = run(frame, size, h, method)
+    assert par == 1 and int(r["status"]) == 0 and int(r["hash"]) == h and int(r["produced"]) == size, (r, par)
+    assert np.array_equal(out[256:256 + size], plain) and (out[:256] == 0xEE).all() and (out[256 + size:] == 0xEE).all()
+    assert int(r2["status"]) == 0 and np.array_equal(out2[256:256 + size], plain)
+    bad = frame.copy(); bad[len(bad) // 2] ^= 0x10
+    r, par, out, r2, out2 = run(bad, size, h, method)
+    assert int(r["status"]) == int(r2["status"]) != 0 and int(r["hash"]) == int(r2["hash"]), (r, r2)
+    r, par, out, r2, out2 = run(frame, size, h ^ 1, method)
+    assert int(r["status"]) == 15 == int(r2["status"]) and np.array_equal(out[256:256 + size], plain)
+    small = dg.fill(dg.RECORDS, 96, 0, 100000)
+    sf = np.frombuffer(dg.compress(method, level, small), dtype=np.uint8)
+    r, par, out, r2, out2 = run(sf, len(small), dg.xxh3(small), method)
+    assert par == 0 and int(r["status"]) == 0 and np.array_equal(out[256:256 + len(small)], small)
+    r, par, out, r2, out2 = run(plain[:3 * M], 3 * M, dg.xxh3(plain[:3 * M]), METHOD_NONE)
+    assert int(r["status"]) == 0 and np.array_equal(out[256:256 + 3 * M], plain[:3 * M])
+
+
 def test_big_entry_damage_gets_the_one_wave_verdict(codec):
     """A frame sequence with a damaged frame, a damaged frame header, a short or long comp_size, a wrong hash, a capacity below the size:
     the frame-parallel reader gives exactly what the one-wave reader gives (status, detail, produced, hash), which is what the oracle

@@ -45,8 +45,33 @@ def one(size, cls_mix, parallel):
     return best, len(frame) / size, st["frame_parallel_entries"], st["frame_parallel_frames"]
 
 
+def one_device(size, cls_mix):
+    """the same entry with its bytes and its output in DEVICE memory (zpk_codec_decode_big_device)"""
+    import torch
+    codec.set_option(zpack_amd.OPT_DEC_SPLIT_MIN, 2 << 20)
+    tile = np.concatenate([dg.fill(cls_mix[k % len(cls_mix)], 5, k, 1 << 20) for k in range(8)])
+    src = np.ascontiguousarray(np.resize(tile, size))
+    frame = np.frombuffer(dg.compress(METHOD, LEVEL, src), dtype=np.uint8)
+    dsrc = torch.zeros(len(frame) + 64, dtype=torch.uint8, device="cuda:0")
+    dsrc[:len(frame)] = torch.from_numpy(frame.copy()).to("cuda:0")
+    ddst = torch.zeros(size + 64, dtype=torch.uint8, device="cuda:0")
+    d = np.zeros(1, dtype=zpack_amd.DECODE_DESC)
+    d["src_offset"] = 0; d["comp_size"] = len(frame); d["uncomp_size"] = size; d["expect_hash"] = dg.xxh3(src); d["dst_capacity"] = size; d["method"] = METHOD
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = codec.decode_big_device(dsrc, d, ddst)
+        best = min(best, time.perf_counter() - t)
+        assert int(r["status"]) == 0
+    assert np.array_equal(ddst[:size].cpu().numpy(), src)
+    return best, codec.decode_stats()["frame_parallel_entries"]
+
+
 for name, mix in (("text+records", (0, 1)), ("text", (0,)), ("byte runs", (3,)), ("random", (2,))):
     t, ratio, par, nb = one(mib << 20, mix, True)
     t1, ratio1, par1, _ = one(mib1 << 20, mix, False)
     print("%-13s one %d MiB %s frame of the reference writer, %d blocks side by side (parallel entries: %d): read %.1f ms = %.2f GiB/s (host pointers in and out), ratio %.3f | "
           "one %d MiB frame, one wave: read %.1f ms = %.3f GiB/s" % (name, mib, "LZ4" if METHOD == zpack_amd.METHOD_LZ4 else "Zstandard-%d" % LEVEL, nb, par, t * 1e3, mib / 1024 / t, ratio, mib1, t1 * 1e3, mib1 / 1024 / t1), flush=True)
+    td, pard = one_device(mib << 20, mix)
+    print("%-13s   the same with the entry and its output in device memory (zpk_codec_decode_big_device, parallel entries: %d): %.1f ms = %.2f GiB/s" % ("", pard, td * 1e3, mib / 1024 / td), flush=True)

@@ -124,6 +124,17 @@ class Codec:
                                                        dst.data_ptr(), dst.numel(), results_dev.data_ptr(), st),
                   "zpk_codec_decode_batch_device")
 
+    def decode_big_device(self, src, desc, dst):
+        """ONE entry: src / dst are uint8 CUDA tensors, desc a one-element np array of DECODE_DESC (host) -> DECODE_RESULT (host, after the
+        entry is decoded and verified)."""
+        self._settle(None)
+        desc = np.ascontiguousarray(desc, dtype=DECODE_DESC)
+        res = np.zeros(1, dtype=DECODE_RESULT)
+        self.L.zpk_codec_decode_big_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        self._chk(self.L.zpk_codec_decode_big_device(self.h, src.data_ptr(), src.numel(), desc.ctypes.data, dst.data_ptr(), dst.numel(), res.ctypes.data),
+                  "zpk_codec_decode_big_device")
+        return res[0]
+
     def encode_batch_device(self, src, desc_dev, n, dst, results_dev, stream=None):
         self._settle(stream)
         st = C.c_void_p(stream) if stream else None
