@@ -167,6 +167,27 @@ def test_one_large_zstd_frame_is_decoded_block_parallel(codec, cls, level):
         assert np.array_equal(out1[i], p) and np.array_equal(out0[i], p), i
 
 
+@pytest.mark.parametrize("level", [9, 15, 19])
+def test_large_zstd_frame_with_repeat_mode_tables_block_parallel(codec, level):
+    """From level 9 on libzstd writes blocks whose sequence tables REPEAT an earlier block's (Repeat_Mode: 32 of 128 text blocks at level 9,
+    112 at 15).  The host walk measures every table description, so a repeating block is told where the table it inherits is described
+    and builds it again itself: such frames are block-parallel too.  Level 19: a window of 8 MiB, matches reaching megabytes back."""
+    sizes = [6 * M + 321, 12 * M]
+    plains = [dg.fill(dg.TEXT if i == 0 else dg.RECORDS, 79, i, n) for i, n in enumerate(sizes)]
+    plains[1][: 6 * M] = dg.fill(dg.TEXT, 80, 1, 6 * M)                      # text, then records: the tables change kind in the middle
+    pay = [np.frombuffer(dg.compress(METHOD_ZSTD, level, p), dtype=np.uint8) for p in plains]
+    want = [dg.xxh3(p) for p in plains]
+    arc, offs, cs = _image(pay)
+    d = _descs(offs, cs, sizes, want, [(METHOD_ZSTD, level)] * len(sizes))
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    r1, out1 = codec.decode_batch_host(arc, d)
+    st = codec.decode_stats()
+    assert st["frame_parallel_entries"] == len(sizes), st
+    assert (r1["status"] == 0).all() and [int(h) for h in r1["hash"]] == want, r1
+    for i, p in enumerate(plains):
+        assert np.array_equal(out1[i], p), i
+
+
 @pytest.mark.parametrize("method", [METHOD_LZ4, METHOD_ZSTD])
 def test_reference_made_large_recipes_block_parallel(codec, golden_dir, method):
     """The LZ4 and Zstandard entries of tests/golden/recipes_big.json (64 MiB text, 64 MiB records, 512 MiB text; sizes, frame checksums

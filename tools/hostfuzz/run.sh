@@ -11,7 +11,7 @@ import re
 s = open("zpack_amd/csrc/zpk_codec.hip").read()
 # the walkers as they are in the source (no copy to drift): frame sequences + one LZ4 frame; then one Zstandard frame
 a = s.index("struct BigSub {"); b = s.index("// The common second half of the block-parallel readers")
-c = s.index("// One block of a Zstandard frame at p"); d = s.index("// -> ZPK_OK with redo = 0: the entry is decoded, its XXH3 is the expected one")
+c = s.index("// Bytes an FSE table description (RFC 8878 4.1.1) takes"); d = s.index("// -> ZPK_OK with redo = 0: the entry is decoded, its XXH3 is the expected one")
 l4 = open("zpack_amd/csrc/lz4_pj.h").read(); zs = open("zpack_amd/csrc/zstd_pj.h").read()
 types = "#define PJ_BLOCK 65536u\n#define ZPJ_BLOCK (128u << 10)\n#define ZPJ_NONE 0xFFFFFFFFu\n#define ZPK_PJ_MIN_BLOCKS 8u\n"
 types += re.search(r"struct PjBlock \{[^}]*\};", l4).group(0) + "\n" + re.search(r"struct ZpjBlock \{.*?\n\};", zs, re.S).group(0) + "\n"

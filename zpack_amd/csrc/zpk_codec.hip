@@ -1619,10 +1619,56 @@ static int decode_big_lz4_single(zpk_codec* c, const u8* archive, const zpk_deco
     return pj_finish(c, d, hb, ZPK_PJ_CHUNK_BLOCKS, d.comp_size, init, true, d_out ? d_out : c->d_dst, dst_ptr, result, redo);
 }
 
+// Bytes an FSE table description (RFC 8878 4.1.1) takes, or -1 (malformed / beyond `avail` / more symbols or accuracy than its kind allows)
+static int zpj_ncount_len(const u8* p, u64 avail, int max_sym, int max_al)
+{
+    u64 bit = 0;
+    auto rd = [&](u32 n) -> i64 {                                   // n <= 16 bits from the LSB-first stream; -1 beyond the bytes
+        if (((bit + n + 7) >> 3) > avail) return -1;
+        u32 v = 0;
+        for (u32 i = 0; i < 4 && (bit >> 3) + i < avail; i++) v |= (u32)p[(bit >> 3) + i] << (8 * i);
+        v = (v >> (bit & 7)) & ((1u << n) - 1u);
+        bit += n;
+        return (i64)v;
+    };
+    i64 x = rd(4);
+    if (x < 0) return -1;
+    const int al = 5 + (int)x;
+    if (al > max_al) return -1;
+    int remaining = 1 << al, s = 0;
+    while (remaining > 0 && s <= max_sym) {
+        int nb = 0; for (u32 t = (u32)remaining + 1; t; t >>= 1) nb++;      // highbit(remaining + 1) + 1
+        x = rd((u32)nb);
+        if (x < 0) return -1;
+        u32 val = (u32)x;
+        const u32 lower_mask = (1u << (nb - 1)) - 1, threshold = (1u << nb) - 1 - ((u32)remaining + 1);
+        if ((val & lower_mask) < threshold) { bit -= 1; val &= lower_mask; }
+        else if (val > lower_mask) val -= threshold;
+        const int proba = (int)val - 1;
+        remaining -= proba < 0 ? 1 : proba;
+        s++;
+        if (proba == 0) {
+            for (;;) {
+                x = rd(2);
+                if (x < 0) return -1;
+                s += (int)x;
+                if (s > max_sym + 1) return -1;
+                if (x != 3) break;
+            }
+        }
+    }
+    if (remaining != 0) return -1;
+    return (int)((bit + 7) >> 3);
+}
+// what governs the three sequence tables at some point of a frame: mode (0 predefined, 1 RLE, 2 FSE description, 3 nothing yet) and
+// where the description starts (offset in the compressed entry)
+struct ZpjTabs { u32 mode[3], off[3]; };
+
 // One block of a Zstandard frame at p (avail bytes follow): 1 = parsed into B (hdr_off = at; sizes, literals and sequence headers; nothing
 // about trees or slots), 0 = the bytes end inside it, -1 = not a block this path takes (reserved type, Repeat_Mode table, sizes that
 // disagree).  *last = its Last_Block bit, *total = 3 + the bytes of its body.
-static int zpj_parse_block(const u8* p, u64 avail, u64 at, ZpjBlock& B, u32* last, u64* total)
+// tabs != nullptr: Repeat_Mode tables are taken — resolved against *tabs, which is updated with what this block defines.
+static int zpj_parse_block(const u8* p, u64 avail, u64 at, ZpjBlock& B, u32* last, u64* total, ZpjTabs* tabs = nullptr)
 {
     if (avail < 3) return 0;
     const u32 bh = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16);
@@ -1664,7 +1710,26 @@ static int zpj_parse_block(const u8* p, u64 avail, u64 at, ZpjBlock& B, u32* las
         else { if (bs - o < 3) return -1; nseq = (u64)b[o + 1] + ((u64)b[o + 2] << 8) + 0x7F00; o += 3; }
         if (bs - o < 1) return -1;
         const u32 modes = b[o];
-        if ((modes & 3) || ((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3) return -1;
+        const bool any_repeat = ((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3;
+        if ((modes & 3) || (any_repeat && !tabs)) return -1;
+        B.tab_modes = 0x3F;
+        if (tabs) {
+            // the three descriptions follow the modes byte in the order LL, OF, ML; each is measured so that the next one's start — and
+            // what a later Repeat_Mode block inherits — is known
+            u64 q = o + 1;
+            for (int kind = 0; kind < 3; kind++) {                     // (T_LL, T_OF, T_ML of zstd_wg.h)
+                const u32 mode = (modes >> (6 - 2 * kind)) & 3;
+                if (mode == 3) {
+                    if (tabs->mode[kind] == 3) return -1;              // nothing to repeat
+                } else {
+                    tabs->mode[kind] = mode; tabs->off[kind] = (u32)(at + 3 + q);
+                    if (mode == 1) { if (bs - q < 1) return -1; q += 1; }
+                    else if (mode == 2) { const int n = zpj_ncount_len(b + q, bs - q, kind == 0 ? 35 : (kind == 1 ? 31 : 52), kind == 1 ? 8 : 9); if (n < 0) return -1; q += (u64)n; }
+                }
+                B.tab_off[kind] = tabs->off[kind];
+                B.tab_modes = (B.tab_modes & ~(3u << (2 * kind))) | (tabs->mode[kind] << (2 * kind));
+            }
+        }
     }
     B.nseq = (u32)nseq;
     return 1;
@@ -1706,9 +1771,10 @@ static bool walk_zstd_single(const u8* p, u64 comp, u64 uncomp, std::vector<ZpjB
     if (hdr <= 0 || (fcs != ~0ull && fcs != uncomp)) return false;
     u64 q = (u64)hdr;
     u32 tree = ZPJ_NONE;
+    ZpjTabs tabs; for (int k = 0; k < 3; k++) { tabs.mode[k] = 3; tabs.off[k] = 0; }
     for (;;) {
         ZpjBlock B; u32 last = 0; u64 total = 0;
-        if (zpj_parse_block(p + q, comp - q, q, B, &last, &total) != 1) return false;
+        if (zpj_parse_block(p + q, comp - q, q, B, &last, &total, &tabs) != 1) return false;
         if (B.type == 2) {
             if (B.lit_type == 2) tree = (u32)blocks.size();
             if (B.lit_type == 3) { if (tree == ZPJ_NONE) return false; B.tree_src = tree; }
@@ -1741,6 +1807,8 @@ static int decode_big_zstd_single(zpk_codec* c, const u8* archive, const zpk_dec
         if (blocks[b].type != 2 || blocks[b].nseq == 0) continue;
         items[b].src_offset = blocks[b].hdr_off; items[b].comp_size = 3ull + blocks[b].size;
         items[b].dst_offset = 8ull * blocks[b].seq_base; items[b].dst_capacity = 8ull * blocks[b].nseq; items[b].method = ZPK_METHOD_ZSTD;
+        items[b].uncomp_size = (u64)blocks[b].tab_off[0] | ((u64)blocks[b].tab_off[1] << 32);         // (k_zstd_fse_blocks: inherited table descriptions)
+        items[b].expect_hash = (u64)blocks[b].tab_off[2] | ((u64)blocks[b].tab_modes << 32);
         list.push_back((u32)b);
     }
     const u64 aux_desc = 0, aux_list = (nb * sizeof(zpk_decode_desc) + 255) & ~255ull, aux_state = aux_list + ((nb * 4 + 255) & ~255ull),
@@ -1776,7 +1844,7 @@ static int decode_big_zstd_single(zpk_codec* c, const u8* archive, const zpk_dec
         const u32 rows = (u32)list.size();
         const u32 grid = (rows + ZF_ROWS - 1) / ZF_ROWS < ZF_GRID_MAX ? (rows + ZF_ROWS - 1) / ZF_ROWS : ZF_GRID_MAX;
         hipLaunchKernelGGL(k_zstd_fse_blocks, dim3(grid), dim3(64), 0, st, (const u8*)c->d_src, (const zpk_decode_desc*)(aux + aux_desc), (const u32*)(aux + aux_list),
-                           c->d_pj_flags + ZPJ_CNT, (u64*)c->d_pj_recs, state, rep_out);
+                           c->d_pj_flags + ZPJ_CNT, (u64*)c->d_pj_recs, state, rep_out, d.comp_size);
     }
     hipLaunchKernelGGL(k_zpj_lit, dim3((u32)nb), dim3(64), 0, st, c->d_src, arena_off + lit_total, arena_off, (const ZpjBlock*)ZB, (u32)nb, c->d_pj_flags);
     hipLaunchKernelGGL(k_zpj_reps, dim3(1), dim3(64), 0, st, ZB, (u32)nb, (const u32*)state, (const u32*)rep_out, c->d_pj_flags);

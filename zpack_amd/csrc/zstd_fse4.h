@@ -215,7 +215,7 @@ enum { ZF_NEED_ENTRY = 0, ZF_NEED_FRAME = 1, ZF_NEED_BLOCK = 2, ZF_DECODING = 3,
 template <bool BLOCKS>
 __device__ __forceinline__ void zstd_fse_rows(ZfShared& sh, const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                               const u32* __restrict__ list, u32* __restrict__ counters,
-                                              u64* __restrict__ arena, u32* __restrict__ state, u32* __restrict__ rep_out)
+                                              u64* __restrict__ arena, u32* __restrict__ state, u32* __restrict__ rep_out, u64 src_size)
 {
     const int lane = lane_id();
     const int row = lane >> 4, sub = lane & 15;
@@ -239,6 +239,7 @@ __device__ __forceinline__ void zstd_fse_rows(ZfShared& sh, const u8* __restrict
     const u8* ip = nullptr; const u8* iend = nullptr;
     u64 a_base = 0; u32 seq_cap = 0, seq_n = 0;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;
+    u32 tab_ll = 0, tab_of = 0, tab_ml = 0, tab_modes = 0x3F;      // BLOCKS: where the table a Repeat_Mode kind inherits is described (offset in src), and how (2 bits per kind; 3 = nowhere)
     bool tables_valid = false, last_block = false, cksum = false, bad = false;
     int al_ll = 0, al_of = 0, al_ml = 0;
     u32 seq_end = 0;                                     // seq_n at the end of the row's current block
@@ -299,6 +300,7 @@ __device__ __forceinline__ void zstd_fse_rows(ZfShared& sh, const u8* __restrict
                     phase = ZF_NEED_FRAME;
                     if constexpr (BLOCKS) {                              // the item IS a block: no frame header, inherited history as symbols
                         rep0 = ZF_SYM(1); rep1 = ZF_SYM(2); rep2 = ZF_SYM(3); tables_valid = false; cksum = false;
+                        tab_ll = (u32)d.uncomp_size; tab_of = (u32)(d.uncomp_size >> 32); tab_ml = (u32)d.expect_hash; tab_modes = (u32)(d.expect_hash >> 32) & 0x3Fu;
                         phase = ZF_NEED_BLOCK;
                     }
                 }
@@ -412,32 +414,47 @@ __device__ __forceinline__ void zstd_fse_rows(ZfShared& sh, const u8* __restrict
                         int pending = 0, ns[3] = {0, 0, 0};
                         #pragma unroll 1
                         for (int kind = 0; kind < 3 && ok; kind++) {      // T_LL, T_OF, T_ML: the order in the stream
-                            const int mode = (int)((modes >> (6 - 2 * kind)) & 3);
+                            int mode = (int)((modes >> (6 - 2 * kind)) & 3);
                             ZPK_LDS u16* const ts = kind == T_LL ? (ZPK_LDS u16*)R->t.c_ll : (kind == T_OF ? (ZPK_LDS u16*)R->t.c_of : (ZPK_LDS u16*)R->t.c_ml);
                             const int max_sym = kind == T_LL ? 35 : (kind == T_OF ? 31 : 52);
                             int al = 0;
+                            // where this kind's description is read: the block's own header, or (BLOCKS, Repeat_Mode) the header of the earlier
+                            // block whose table it inherits — the host walk knows which (zstd_pj.h)
+                            u128 stg = stage; u32 oo = o, av = avail; bool inherited = false;
+                            if constexpr (BLOCKS) if (mode == 3) {
+                                const u32 toff = kind == T_LL ? tab_ll : (kind == T_OF ? tab_of : tab_ml);
+                                mode = (int)((tab_modes >> (2 * kind)) & 3u);
+                                if (mode == 3 || (u64)toff >= src_size) { ok = false; mode = 3; }
+                                else {
+                                    const u64 rem = src_size - toff;
+                                    av = rem < 256 ? (u32)rem : 256u;
+                                    stg = zf_load16(src + toff, (i32)av, 16 * sub);
+                                    oo = 0; inherited = true;
+                                }
+                            }
                             if (mode == 0) {
                                 const ZPK_LDS u16* const dfs = kind == T_LL ? (const ZPK_LDS u16*)sh.d_ll : (kind == T_OF ? (const ZPK_LDS u16*)sh.d_of : (const ZPK_LDS u16*)sh.d_ml);
                                 const int n = kind == T_OF ? 32 : 64;
                                 for (int i = sub; i < n; i += 16) ts[i] = dfs[i];
                                 al = kind == T_OF ? 5 : 6;
                             } else if (mode == 1) {
-                                if (o >= avail) ok = false;
+                                if (oo >= av) ok = false;
                                 else {
-                                    const u32 s = zf_stage_bits(stage, 8u * o, lane) & 0xFFu;
+                                    const u32 s = zf_stage_bits(stg, 8u * oo, lane) & 0xFFu;
                                     if ((int)s > max_sym) ok = false;
-                                    else { ts[0] = (u16)(1u | (s << 10)); al = 0; o += 1; }      // one cell: counter 1 -> no state bits, next state 0
+                                    else { ts[0] = (u16)(1u | (s << 10)); al = 0; oo += 1; }      // one cell: counter 1 -> no state bits, next state 0
                                 }
                             } else if (mode == 2) {
                                 int nsym = 0;
-                                const int used2 = o < avail ? zf_read_ncount(stage, o, avail - o, 272u - o, max_sym, kind == T_OF ? 8 : 9,
-                                                                             (ZPK_LDS i16*)R->ncount + zf_nc_base(kind), nsym, al, lane) : -1;
+                                const int used2 = oo < av ? zf_read_ncount(stg, oo, av - oo, 272u - oo, max_sym, kind == T_OF ? 8 : 9,
+                                                                           (ZPK_LDS i16*)R->ncount + zf_nc_base(kind), nsym, al, lane) : -1;
                                 if (used2 < 0) ok = false;
-                                else { o += (u32)used2; ns[kind] = nsym; pending |= 1 << kind; }
+                                else { oo += (u32)used2; ns[kind] = nsym; pending |= 1 << kind; }
                             } else {
-                                if (!tables_valid) ok = false;
+                                if (BLOCKS || !tables_valid) ok = false;
                                 al = kind == T_LL ? al_ll : (kind == T_OF ? al_of : al_ml);
                             }
+                            if (!inherited) o = oo;
                             if (kind == T_LL) al_ll = al; else if (kind == T_OF) al_of = al; else al_ml = al;
                         }
                         if (ok) {
@@ -574,15 +591,15 @@ __global__ __launch_bounds__(64, 3) void k_zstd_fse(const u8* __restrict__ src, 
 {
     if (counters[ZF_COUNT_WORD] == 0) return;        // no Zstandard entry in the batch
     __shared__ ZfShared sh;
-    zstd_fse_rows<false>(sh, src, desc, list, counters, arena, state, nullptr);
+    zstd_fse_rows<false>(sh, src, desc, list, counters, arena, state, nullptr, 0);
 }
 __global__ __launch_bounds__(64, 3) void k_zstd_fse_blocks(const u8* __restrict__ src, const zpk_decode_desc* __restrict__ desc,
                                                         const u32* __restrict__ list, u32* __restrict__ counters,
-                                                        u64* __restrict__ arena, u32* __restrict__ state, u32* __restrict__ rep_out)
+                                                        u64* __restrict__ arena, u32* __restrict__ state, u32* __restrict__ rep_out, u64 src_size)
 {
     if (counters[ZF_COUNT_WORD] == 0) return;
     __shared__ ZfShared sh;
-    zstd_fse_rows<true>(sh, src, desc, list, counters, arena, state, rep_out);
+    zstd_fse_rows<true>(sh, src, desc, list, counters, arena, state, rep_out, src_size);
 }
 
 }  // namespace zpk

@@ -8,8 +8,9 @@
 //                                            final histories gives every symbol its value (k_zpj_reps);
 //   * a Huffman table (Treeless literals) -> the block reads the tree description of the block it inherits from itself (the host walk
 //                                            knows which: nearly every block of a text frame is treeless);
-//   * FSE tables (Repeat_Mode)            -> not taken: such a frame is decoded by the one-wave decoder (libzstd 1.4.9 at levels 1-3
-//                                            wrote none in 4 x 512 blocks of the benchmark corpus).
+//   * FSE tables (Repeat_Mode)            -> the block builds the table again from the description in the header of the block it
+//                                            inherits from (the host walk knows where each description starts: it measures them);
+//                                            libzstd 1.4.9 writes such blocks from level 9 on (text: 32 of 128 blocks at level 9, 112 at 15).
 // Steps (all blocks side by side in each):
 //   host        walks the block headers, literals-section headers and sequence-section headers (a few bytes per block): ZpjBlock table;
 //   k_zstd_fse_blocks   sequences of every block -> 8-byte records (offset | match length | literal length), offsets symbolic where inherited;
@@ -43,6 +44,8 @@ struct ZpjBlock {
     u32 nseq;                // ... sequences
     u32 seq_base;            // ... index of its first sequence record (a block owns nseq + 1 slots: the last one stands for the trailing literals)
     u32 rep_in[3];           // device (k_zpj_reps): repeat offsets at the block's start
+    u32 tab_off[3];          // ... a Repeat_Mode table (LL, OF, ML): where the table it inherits is described (offset in the compressed entry)
+    u32 tab_modes;           // ... and how: 2 bits per kind (0 predefined, 1 RLE, 2 FSE description, 3 nowhere)
 };
 // words of the flags array this path adds (lz4_pj.h: PJ_ERR, PJ_TOTAL, PJ_ROUND0 ..): the counters k_zstd_fse_blocks works with
 #define ZPJ_CNT 40                                 // flags + ZPJ_CNT = its `counters` (ZF_COUNT_WORD 1, ZF_HEAD 8, ZF_WATCHDOG_WORD 11..13)
