@@ -528,11 +528,12 @@ def _stream_decode(codec, frame, method, uncomp_size, want_hash, chunk, out_chun
     return status, bytes(out), first
 
 
-@pytest.mark.parametrize("level", [1, 3])
+@pytest.mark.parametrize("level", [1, 3, 9, 15])
 def test_stream_large_zstd_entry_goes_in_bounded_block_parallel_steps(codec, level):
     """The same for one plain Zstandard frame (lib/zpack_write.c:179): steps of up to 64 blocks behind the frame's window; the repeat
-    offsets, the running XXH3 and the last block with a Huffman tree travel from step to step."""
-    size = 40 << 20
+    offsets, the running XXH3, the last block with a Huffman tree and the table descriptions in force (levels >= 9: Repeat_Mode blocks)
+    travel from step to step."""
+    size = (40 << 20) if level <= 3 else (20 << 20)
     tile = np.concatenate([dg.fill(k % 2, 43, k, 1 << 20) for k in range(8)])
     plain = np.ascontiguousarray(np.resize(tile, size))
     frame = dg.compress(dg.ZSTD, level, plain)
