@@ -63,9 +63,10 @@ CASES = [(METHOD_LZ4, 0, 2 * M), (METHOD_LZ4, 0, 3 * M + 17), (METHOD_ZSTD, 3, 2
          (METHOD_LZ4, 0, 2 * M - 1), (METHOD_ZSTD, 1, 300000), (METHOD_NONE, 0, 70000), (METHOD_LZ4, 9, 5 * M), (METHOD_ZSTD, 1, 33 * M + 777)]
 
 
-def test_big_entries_frame_parallel_equals_one_wave(codec):
-    """Written split, read frame-parallel; the same archive read with the split switched off; an unsplit writing of the same
-    plaintexts: every variant gives the same bytes, hashes (the real xxHash's) and produced counts, and the counters say which path ran."""
+def test_big_entries_written_in_pieces_read_block_parallel_equal_one_wave(codec):
+    """Written in pieces (one frame per entry, its blocks compressed 512 KiB piece by piece), read block-parallel; the same archive read by
+    one wave per entry; an unsplit writing of the same plaintexts: every variant gives the same bytes, hashes (the real xxHash's) and
+    produced counts, and the counters say which path ran.  Then a SEQUENCE of frames as one entry (what round 4 wrote): one wave per frame."""
     plains = [dg.fill(i % 4, 321, i, n) for i, (_, _, n) in enumerate(CASES)]
     methods = [(m, lv) for m, lv, _ in CASES]
     sizes = [n for _, _, n in CASES]
@@ -76,11 +77,12 @@ def test_big_entries_frame_parallel_equals_one_wave(codec):
     arc, offs, cs = _image(pay)
     d = _descs(offs, cs, sizes, res["hash"], methods)
     nbig = sum(1 for n in sizes if n >= 2 * M)
-    nframes = sum((n + PIECE - 1) // PIECE for n in sizes if n >= 2 * M)
+    # stored: slices of 512 KiB; LZ4: its 64 KiB blocks; Zstandard: its 64 KiB blocks + the empty block that closes a frame written in pieces
+    nunits = sum(((n + PIECE - 1) // PIECE) if m == METHOD_NONE else ((n + 65535) // 65536 + (1 if m == METHOD_ZSTD else 0)) for (m, _, n) in CASES if n >= 2 * M)
     codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
     r1, out1 = codec.decode_batch_host(arc, d)
     st = codec.decode_stats()
-    assert st["frame_parallel_entries"] == nbig and st["frame_parallel_frames"] == nframes, st
+    assert st["frame_parallel_entries"] == nbig and st["frame_parallel_frames"] == nunits, (st, nbig, nunits)
     codec.set_option(OPT_DEC_SPLIT_MIN, 0)
     r0, out0 = codec.decode_batch_host(arc, d)
     st = codec.decode_stats()
@@ -89,7 +91,7 @@ def test_big_entries_frame_parallel_equals_one_wave(codec):
         assert (r["status"] == 0).all() and [int(h) for h in r["hash"]] == want and [int(x) for x in r["produced"]] == sizes
     for i, p in enumerate(plains):
         assert np.array_equal(out1[i], p) and np.array_equal(out0[i], p), i
-    # the checkers on the split payloads
+    # the checkers on the payloads written in pieces
     o = oracle()
     arc_b = arc.tobytes()
     for i, p in enumerate(plains):
@@ -97,7 +99,7 @@ def test_big_entries_frame_parallel_equals_one_wave(codec):
             continue
         rc, out, got, h = o.entry_decode(arc_b, int(offs[i]), int(cs[i]), sizes[i], want[i], methods[i][0], sizes[i])
         assert rc == 0 and out == p.tobytes(), (i, rc)
-    # unsplit writing: other bytes, same plaintext behind them; the read path finds nothing to split
+    # unsplit writing: other bytes, same plaintext behind them, read the same way
     codec.set_option(OPT_ENC_SPLIT_MIN, 0)
     res2, pay2 = _encode(codec, plains[:5], methods[:5])
     assert [int(h) for h in res2["hash"]] == want[:5]
@@ -105,11 +107,19 @@ def test_big_entries_frame_parallel_equals_one_wave(codec):
     codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
     r2, out2 = codec.decode_batch_host(arc2, _descs(offs2, cs2, sizes[:5], res2["hash"], methods[:5]))
     st = codec.decode_stats()
-    # (the stored entry: slices need no frames; the two LZ4 and the two Zstandard entries of >= 2 MiB, ONE frame each: block-parallel,
-    # lz4_pj.h / zstd_pj.h — here on frames of this library's own encoder: 64 KiB blocks, repeat-offset codes)
     assert (r2["status"] == 0).all() and st["frame_parallel_entries"] == 5, st
     for i in range(5):
         assert np.array_equal(out2[i], plains[i])
+    # ---- a sequence of frames with content sizes as ONE entry (archives of round 4; lib/zpack_read.c:380 continues with the next frame) ----
+    big = dg.fill(dg.TEXT, 322, 0, 5 * PIECE + 777)
+    parts = [big[k:k + PIECE] for k in range(0, len(big), PIECE)]
+    resp, payp = _encode(codec, parts, [(METHOD_ZSTD, 3)] * len(parts))
+    seq = np.concatenate(payp)
+    arc3, offs3, cs3 = _image([seq])
+    d3 = _descs(offs3, cs3, [len(big)], [dg.xxh3(big)], [(METHOD_ZSTD, 3)])
+    r3, out3 = codec.decode_batch_host(arc3, d3)
+    st = codec.decode_stats()
+    assert int(r3["status"][0]) == 0 and np.array_equal(out3[0], big) and st["frame_parallel_entries"] == 1 and st["frame_parallel_frames"] == len(parts), st
     codec.set_option(OPT_ENC_SPLIT_MIN, 2 * M)
 
 
@@ -403,7 +413,9 @@ def test_big_entry_damage_gets_the_one_wave_verdict(codec):
             if label == "intact":
                 assert par == 1 and r1["status"][0] == 0
             if label == "hash":
-                assert par == 1 and r1["status"][0] == 15 and np.array_equal(out1[0][:len(plain)], plain), key    # the bytes stay, like the reference's
+                # the bytes stay, like the reference's (a Zstandard frame with a wrong XXH3 gets its verdict from the one-wave decoder: its
+                # blocks carry no checksum, the block-parallel reader cannot tell a wrong expectation from a damaged block)
+                assert par == (0 if method == METHOD_ZSTD else 1) and r1["status"][0] == 15 and np.array_equal(out1[0][:len(plain)], plain), key
             if not label.startswith("flip") or int(label[5:]) % 7 == 0 or len(variants) < 40:
                 rc, out, got, hh = o.entry_decode(arc.tobytes(), int(offs[0]), csize, len(plain), eh, method, cap)
                 assert rc == int(r1["status"][0]), (key, rc, r1)
@@ -434,13 +446,14 @@ def test_big_entry_through_zpack_h_and_the_compiled_reference(tmp_path):
 
 def test_split_options_through_the_environment_of_zpack_h(monkeypatch):
     """zpack.h has no place for codec options: a context reads ZPACK_AMD_ENC_SPLIT_MIN / _DEC_SPLIT_MIN when it is created.  0 = one
-    frame per entry whatever its size (byte-identical archives across library versions), the default cuts at 2 MiB."""
+    wave per entry whatever its size (byte-identical archives across library versions), the default cuts at 2 MiB.  Either way an entry
+    is ONE frame; an entry written in pieces differs in a few bytes (a piece's first block has no match into the piece before it)."""
     from tests._libs import ZPackAPI
     from tests import zpk
     from tests.test_gpu_zpack_api import _count_frames
     Z = ZPackAPI(zpack_amd.ZPACK_SO)
     plain = dg.fill(dg.TEXT, 8, 2, 3 * M + 5).tobytes()
-    frames = {}
+    payloads = {}
     for setting in ("0", None, str(1 << 20)):
         if setting is None:
             monkeypatch.delenv("ZPACK_AMD_ENC_SPLIT_MIN", raising=False)
@@ -448,11 +461,14 @@ def test_split_options_through_the_environment_of_zpack_h(monkeypatch):
             monkeypatch.setenv("ZPACK_AMD_ENC_SPLIT_MIN", setting)
         arc = Z.write_archive([("f", plain), ("g", plain[:(3 * M) // 2])], METHOD_LZ4, 0)       # (a writer makes its context on first use)
         ents = zpk.parse(arc)
-        frames[setting] = [_count_frames(arc[e["offset"]:e["offset"] + e["comp_size"]], METHOD_LZ4) for e in ents]
+        payloads[setting] = [arc[e["offset"]:e["offset"] + e["comp_size"]] for e in ents]
+        assert [_count_frames(x, METHOD_LZ4) for x in payloads[setting]] == [1, 1]
         rc, r, keep = Z.open_memory(arc)
         assert rc == 0
         for i, want in enumerate((plain, plain[:(3 * M) // 2])):
             rc, out = Z.read_file(r, i, len(want))
             assert rc == 0 and out == want
         Z.close_reader(r)
-    assert frames["0"] == [1, 1] and frames[None] == [7, 1] and frames[str(1 << 20)] == [7, 3], frames
+    # f (3 MiB): in pieces by default and at 1 MiB, not at 0; g (1.5 MiB): in pieces only at 1 MiB
+    assert payloads[None][0] == payloads[str(1 << 20)][0] != payloads["0"][0]
+    assert payloads[None][1] == payloads["0"][1] != payloads[str(1 << 20)][1]

@@ -720,40 +720,45 @@ def test_stream_roundtrips_random_sizes_and_windows(Z, tmp_path):
         assert rc == 0 and np.array_equal(np.frombuffer(out, dtype=np.uint8, count=size), plain), (it, size, method, rc)
 
 
-def _count_frames(payload, method):
-    """frames in an entry's payload, walked by their own block headers (LZ4F: 64 KiB blocks, no checksums; Zstandard: single-segment
-    frames without checksum — the flavours the device encoder writes)"""
+def _count_frames(payload, method, blocks=None):
+    """frames in an entry's payload, walked by their own block headers (LZ4F: 64 KiB blocks, no checksums; Zstandard: frames without
+    checksum or dictionary — the flavours the device encoder writes); blocks (a list): gets the number of blocks of every frame"""
     p = n = 0
     b = payload
     while p < len(b):
+        nb = 0
         if method == METHOD_LZ4:
             assert b[p:p + 4] == bytes([0x04, 0x22, 0x4D, 0x18]), p
-            p += 15 if b[p + 4] & 0x08 else 7                                          # (a piece of a sequence states its content size)
+            p += 15 if b[p + 4] & 0x08 else 7
             while True:
                 w = int.from_bytes(b[p:p + 4], "little"); p += 4
                 if w == 0:
                     break
-                p += w & 0x7FFFFFFF
+                p += w & 0x7FFFFFFF; nb += 1
         else:
             assert b[p:p + 4] == bytes([0x28, 0xB5, 0x2F, 0xFD]), p
             fhd = b[p + 4]
-            assert fhd & 0x20 and not fhd & 0x04
-            p += 5 + [1, 2, 4, 8][fhd >> 6]
+            assert not fhd & 0x0F
+            single, fcs = (fhd >> 5) & 1, fhd >> 6
+            p += 5 + (0 if single else 1) + ([1, 2, 4, 8][fcs] if (single or fcs) else 0)
             while True:
                 w = int.from_bytes(b[p:p + 3], "little"); p += 3
                 p += 1 if (w >> 1) & 3 == 1 else w >> 3
+                nb += 1
                 if w & 1:
                     break
         n += 1
+        if blocks is not None:
+            blocks.append(nb)
     assert p == len(b)
     return n
 
 
-def test_large_entries_are_written_as_frame_sequences(Z):
-    """zpack_write_files: an entry of >= 2 MiB goes to the device as 512 KiB pieces, one wave and one FRAME each, and its XXH3 is computed
-    by the whole chip (per-block partial sums + one chain) — sizes around the switch, around the piece and around XXH3's 1 KiB block /
-    64-byte stripe edges, every method; checked by the oracle, the compiled reference (both continue with the next frame, as
-    lib/zpack_read.c:380 and :414-439 do) and this library's own reader."""
+def test_large_entries_are_written_as_one_frame_in_pieces(Z):
+    """zpack_write_files: an entry of >= 2 MiB goes to the device as 512 KiB pieces, one wave each, and comes out as ONE frame — the layout
+    of the reference writer (lib/zpack_write.c:179, :204-210; round 4 wrote a frame per piece) — its XXH3 computed by the whole chip
+    (per-block partial sums + one chain): sizes around the switch, around the piece and around XXH3's 1 KiB block / 64-byte stripe
+    edges, every method; checked by the oracle, the compiled reference and this library's own reader."""
     M = 1 << 20
     cases = [(METHOD_LZ4, 0, 2 * M - 1), (METHOD_LZ4, 0, 2 * M), (METHOD_LZ4, 0, 3 * M + 17), (METHOD_LZ4, 9, 2 * M + 1),
              (METHOD_ZSTD, 3, 2 * M), (METHOD_ZSTD, 1, 5 * M - 1), (METHOD_ZSTD, 1, 2 * M + (512 << 10) + 1), (METHOD_ZSTD, 3, 100000),
@@ -782,8 +787,11 @@ def test_large_entries_are_written_as_frame_sequences(Z):
     for e, (m, lv, n) in zip(ents, cases):
         assert e["method"] == m
         if m != METHOD_NONE:
-            frames = _count_frames(arc[e["offset"]:e["offset"] + e["comp_size"]], m)
-            assert frames == ((n + (512 << 10) - 1) // (512 << 10) if n >= 2 * M else 1), (m, n, frames)
+            nblocks = []
+            frames = _count_frames(arc[e["offset"]:e["offset"] + e["comp_size"]], m, nblocks)
+            assert frames == 1, (m, n, frames)
+            # 64 KiB blocks; a Zstandard frame written in pieces is closed by an empty last block
+            assert nblocks[0] == (n + 65535) // 65536 + (1 if (m == METHOD_ZSTD and n >= 2 * M) else 0), (m, n, nblocks)
         else:
             assert e["comp_size"] == n
     rc, r, keepr = Z.open_memory(arc)
