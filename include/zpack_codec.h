@@ -93,9 +93,11 @@ typedef struct zpk_encode_desc {
     int32_t  level;
 } zpk_encode_desc;
 
-/* The entry is one frame of a SEQUENCE of frames that together are an archive entry (large entries of the host path, the streaming
- * writer): an LZ4 frame then carries its content size in the header (a Zstandard frame always does), so that a reader can place the
- * frames' outputs without decoding them — and decode them side by side; result.hash is left 0 (the entry's hash covers all frames). */
+/* The "entry" is a PIECE of a larger archive entry (large entries of the host write path, the streaming writer): its output is a run of
+ * BLOCKS — no frame header, no EndMark / Last_Block — that whoever assembles the entry puts between a frame header and the end of the
+ * frame (LZ4: the EndMark; Zstandard: an empty last block), so that the entry is ONE frame as the reference writer produces it
+ * (lib/zpack_write.c:179, :204-210; round 4 made every piece a frame of its own: ABI 3 changed the meaning).  A piece's blocks do not
+ * refer to the piece before it.  result.hash is left 0 (the entry's hash covers all pieces). */
 #define ZPK_EF_PIECE 0x80000000u
 
 typedef struct zpk_encode_result {

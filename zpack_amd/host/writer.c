@@ -262,7 +262,7 @@ int zpack_write_files_from_archive(zpack_writer* writer, zpack_reader* reader, z
 
 /* streaming write (lib/zpack_write.c:461-685): the plaintext goes to the device chunk by chunk and is compressed there as it comes —
  * every call hands what has been compressed so far to the archive through the caller's output window, as the reference does with
- * its library buffers (:541-571); the entry is a sequence of frames (zpk_stream.inc). */
+ * its library buffers (:541-571); the entry is one frame, its blocks compressed piece by piece (zpk_stream.inc). */
 static int stream_drain(zpack_writer* writer, zpack_stream* stream, zi_stream_state* st)
 {
     for (;;) {
