@@ -198,6 +198,29 @@ def test_large_zstd_frame_with_repeat_mode_tables_block_parallel(codec, level):
         assert np.array_equal(out1[i], p), i
 
 
+def test_many_medium_entries_stay_one_wave_each_while_a_huge_one_goes_block_parallel(codec):
+    """The block-parallel reader takes one entry at a time (each fills the chip); the usual batch runs all its entries side by side.  A
+    batch of many 2-3 MiB entries is done in the time of one of them there, so they stay one wave each; a 40 MiB entry among them is the
+    long pole and goes block-parallel.  Same bytes and verdicts either way."""
+    sizes = [2 * M + 7 * i for i in range(24)] + [40 * M + 1]
+    plains = [dg.fill(i % 2, 97, i, n) for i, n in enumerate(sizes)]
+    pay = [np.frombuffer(dg.compress(METHOD_LZ4, 0, p), dtype=np.uint8) for p in plains]
+    want = [dg.xxh3(p) for p in plains]
+    arc, offs, cs = _image(pay)
+    d = _descs(offs, cs, sizes, want, [(METHOD_LZ4, 0)] * len(sizes))
+    codec.set_option(OPT_DEC_SPLIT_MIN, 2 * M)
+    r1, out1 = codec.decode_batch_host(arc, d)
+    st = codec.decode_stats()
+    assert 1 <= st["frame_parallel_entries"] <= 3, st                             # the 40 MiB entry (and at most a couple within the estimate's slack)
+    assert (r1["status"] == 0).all() and [int(h) for h in r1["hash"]] == want
+    for i, p in enumerate(plains):
+        assert np.array_equal(out1[i], p), i
+    # the medium entries alone: none is worth a turn of its own
+    r2, out2 = codec.decode_batch_host(arc, d[:24])
+    st = codec.decode_stats()
+    assert st["frame_parallel_entries"] <= 2 and (r2["status"] == 0).all(), st
+
+
 @pytest.mark.parametrize("method", [METHOD_LZ4, METHOD_ZSTD])
 def test_reference_made_large_recipes_block_parallel(codec, golden_dir, method):
     """The LZ4 and Zstandard entries of tests/golden/recipes_big.json (64 MiB text, 64 MiB records, 512 MiB text; sizes, frame checksums
