@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer: ONE large entry through the host paths (what zpack_write_file / zpack_read_file call with a batch of one) — written as
-a sequence of 512 KiB frames side by side and read back one wave per frame (ZPK_OPT_ENC_SPLIT_MIN / ZPK_OPT_DEC_SPLIT_MIN, default
+a sequence of 512 KiB pieces side by side (one frame) and read back one wave per frame (ZPK_OPT_ENC_SPLIT_MIN / ZPK_OPT_DEC_SPLIT_MIN, default
 2 MiB) against one wave on one frame.
 usage: big_entry_rate.py [MiB=256] [MiB_one_wave=16]"""
 import ctypes as C
@@ -59,5 +59,5 @@ def one(size, method, level, split):
 for method, level, name in [(zpack_amd.METHOD_LZ4, 0, "lz4"), (zpack_amd.METHOD_ZSTD, 1, "zstd-1"), (zpack_amd.METHOD_ZSTD, 3, "zstd-3"), (zpack_amd.METHOD_NONE, 0, "stored")]:
     t, tr, r = one(mib << 20, method, level, True)
     t1, tr1, r1 = one(mib1 << 20, method, level, False)
-    print("%-7s one %d MiB entry, %d frames side by side: write %.1f ms = %.2f GiB/s, read %.1f ms = %.2f GiB/s (host pointers in and out), ratio %.4f | one %d MiB entry, one frame, one wave: write %.1f ms = %.3f GiB/s, read %.1f ms = %.3f GiB/s, ratio %.4f"
+    print("%-7s one %d MiB entry, %d pieces side by side (one frame): write %.1f ms = %.2f GiB/s, read %.1f ms = %.2f GiB/s (host pointers in and out), ratio %.4f | one %d MiB entry, one frame, one wave: write %.1f ms = %.3f GiB/s, read %.1f ms = %.3f GiB/s, ratio %.4f"
           % (name, mib, (mib << 20) // (512 << 10), t * 1e3, mib / 1024 / t, tr * 1e3, mib / 1024 / tr, r, mib1, t1 * 1e3, mib1 / 1024 / t1, tr1 * 1e3, mib1 / 1024 / tr1, r1), flush=True)
