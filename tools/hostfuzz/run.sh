@@ -13,7 +13,7 @@ s = open("zpack_amd/csrc/zpk_codec.hip").read()
 a = s.index("struct BigSub {"); b = s.index("// The common second half of the block-parallel readers")
 c = s.index("// Bytes an FSE table description (RFC 8878 4.1.1) takes"); d = s.index("// -> ZPK_OK with redo = 0: the entry is decoded, its XXH3 is the expected one")
 l4 = open("zpack_amd/csrc/lz4_pj.h").read(); zs = open("zpack_amd/csrc/zstd_pj.h").read()
-types = "#define PJ_BLOCK 65536u\n#define ZPJ_BLOCK (128u << 10)\n#define ZPJ_NONE 0xFFFFFFFFu\n#define ZPK_PJ_MIN_BLOCKS 8u\n"
+types = "#define PJ_BLOCK 65536u\n#define ZPJ_BLOCK (128u << 10)\n#define ZPJ_NONE 0xFFFFFFFFu\n#define ZPK_PJ_MIN_BLOCKS 4u\n#define ZPK_ZPJ_MIN_BLOCKS 2u\n"
 types += re.search(r"struct PjBlock \{[^}]*\};", l4).group(0) + "\n" + re.search(r"struct ZpjBlock \{.*?\n\};", zs, re.S).group(0) + "\n"
 t = open("tools/hostfuzz/walk_fuzz_main.cpp.in").read().replace("/*@TYPES@*/", types).replace("/*@WALKERS@*/", s[a:b] + s[c:d])
 open("/tmp/zpk_hostfuzz/walk_fuzz.cpp", "w").write(t)

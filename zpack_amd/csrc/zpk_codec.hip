@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void k_hash(const u8* __restrict__ src, const 
 
 // ------------------------------------------------------------------------------------ host side
 
-#define ZPK_DEC_SPLIT_MIN_DEFAULT (2ull << 20)
+#define ZPK_DEC_SPLIT_MIN_DEFAULT (256ull << 10)     // (round 5: a single 512 KiB LZ4 entry is 0.66 ms block-parallel against 3.3 ms by one wave, 1 MiB of Zstandard 4.3 against 31.7: tools/mid_entry_rate.py)
 #define ZPK_ENC_SPLIT_MIN_DEFAULT (2ull << 20)
 #define ZPK_ENC_PIECE (512u << 10)                 // = ZPK_CS_PIECE of the streaming writer
 #ifndef ZPK_PJ_CHUNK_BLOCKS
@@ -1438,7 +1438,8 @@ static u32 host_xxh32_small(const u8* p, u32 len)
     return h;
 }
 #ifndef ZPK_PJ_MIN_BLOCKS
-#define ZPK_PJ_MIN_BLOCKS 8u
+#define ZPK_PJ_MIN_BLOCKS 4u                          // LZ4: 256 KiB (fewer blocks: the fixed ~0.6 ms is not earned back)
+#define ZPK_ZPJ_MIN_BLOCKS 2u                         // Zstandard: 2 blocks (the serial FSE chain of ONE block, ~3.5 ms, is the fixed cost either way)
 #endif
 // The entry is ONE frame of 64 KiB blocks, nothing optional but a content size that agrees with the entry, nothing behind its EndMark:
 // its block table (offsets relative to the entry).  Anything else: false (the one-wave decoder's).
@@ -1788,7 +1789,7 @@ static bool walk_zstd_single(const u8* p, u64 comp, u64 uncomp, std::vector<ZpjB
         if (last) break;
         if (slots > 0x7FFFFF00ull || lit_total > 0x70000000ull) return false;
     }
-    if (q != comp || blocks.size() < ZPK_PJ_MIN_BLOCKS) return false;
+    if (q != comp || blocks.size() < ZPK_ZPJ_MIN_BLOCKS) return false;
     return comp + lit_total + 1024 < 0x7FFFFF00ull;
 }
 
@@ -2006,13 +2007,19 @@ int zpk_codec_decode_batch_host(zpk_codec* c, const uint8_t* archive, uint64_t a
         }
         // ---- everything else, and the entries a frame of which did not decode, through the usual path ----
         for (u64 k = 0; k < be.size(); k++) if (!redo[k]) is_big[be[k].idx] = 1;
-        // Which single frames go block-parallel.  One at a time, each fills the chip: ~1.2 ms of fixed cost + its bytes at ~15 GiB/s —
-        // while the entries of the usual batch all run side by side, one wave each (0.15 GiB/s LZ4, 0.035 GiB/s Zstandard): a batch of a
-        // hundred 3 MiB entries is done in the time of ONE of them there.  The batch's time is (the block-parallel entries, one after the
+        // Which single frames go block-parallel.  One at a time, each fills the chip: a fixed cost + its bytes at ~12 GiB/s — while the
+        // entries of the usual batch all run side by side, one wave each: a batch of a hundred 3 MiB entries is done in the time of ONE
+        // of them there.  The batch's time is (the block-parallel entries, one after the
         // other) + (the longest one-wave entry left): the largest entries go block-parallel as long as that sum shrinks.
-        if (pj.size() > 1) {
-            auto wave_ms = [&](u64 i) { return (double)desc[i].uncomp_size / (1 << 20) / (desc[i].method == ZPK_METHOD_LZ4 ? 0.15 : 0.035) / 1.024; };
-            auto pj_ms = [&](u64 i) { return 1.2 + (double)desc[i].uncomp_size / (1 << 20) / 15.0 / 1.024; };
+        if (!pj.empty()) {
+            // (measured, tools/mid_entry_rate.py + big_frame_rate.py: one wave 0.15 GiB/s LZ4 — ~1 GiB/s when the entry did not compress —,
+            // 0.031 GiB/s Zstandard; block-parallel 0.6 ms + 12 GiB/s LZ4, 4.2 ms + 12 GiB/s Zstandard)
+            auto wave_ms = [&](u64 i) {
+                const double mib = (double)desc[i].uncomp_size / (1 << 20);
+                const bool stored_like = desc[i].comp_size >= desc[i].uncomp_size - desc[i].uncomp_size / 16;
+                return mib / 1.024 / (desc[i].method == ZPK_METHOD_LZ4 ? (stored_like ? 1.0 : 0.15) : (stored_like ? 0.9 : 0.031));
+            };
+            auto pj_ms = [&](u64 i) { return (desc[i].method == ZPK_METHOD_LZ4 ? 0.6 : 4.2) + (double)desc[i].uncomp_size / (1 << 20) / 12.0 / 1.024; };
             std::sort(pj.begin(), pj.end(), [&](const PjEntry& a, const PjEntry& b) { return wave_ms(a.idx) > wave_ms(b.idx); });
             double other = 0;                                                         // the longest entry that is not a candidate at all
             { std::vector<u8> cand(n, 0); for (auto& P : pj) cand[P.idx] = 1;
