@@ -65,7 +65,8 @@ h)   # round 5: ONE large frame of the reference writer through the host read pa
   timeout -k 10 300 python3 tools/big_frame_rate.py 256 8 zstd 3 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_zstd_frame_rate.txt
   timeout -k 10 300 python3 tools/big_frame_rate.py 256 8 zstd 1 2>&1 | grep -v amdgpu.ids | tee -a $out/${tag}_big_zstd_frame_rate.txt
   timeout -k 10 600 python3 tools/stream_rate.py lz4_0_64m_text,lz4_0_64m_records,lz4_0_512m_text,zstd_3_64m_text,zstd_3_64m_records,zstd_3_512m_text 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_stream_read_rate.txt
-  timeout -k 10 400 python3 tools/big_entry_rate.py 256 16 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_entry_rate.txt ;;
+  timeout -k 10 400 python3 tools/big_entry_rate.py 256 16 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_big_entry_rate.txt
+  timeout -k 10 300 python3 tools/mid_entry_rate.py 2>&1 | grep -v amdgpu.ids | tee $out/${tag}_mid_entry_rate.txt ;;
 f)
   # soak of the streaming write / read pair: random entry sizes, chunkings and windows (the suite runs 30 of these; here 600 more, other seed)
   ZPK_STREAM_FUZZ_ITERS=600 ZPK_STREAM_FUZZ_SEED=7 timeout -k 10 1000 python -m pytest tests/test_gpu_zpack_api.py -x -q -m gpu -k random_sizes_and_windows > $out/${tag}_stream_soak.log 2>&1; echo "stream soak rc=$?" | tee -a $out/${tag}_stream_soak.log; tail -4 $out/${tag}_stream_soak.log
