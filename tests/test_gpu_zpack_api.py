@@ -411,6 +411,24 @@ def test_stream_read_is_bounded_and_incremental(Z, golden_dir, label):
         assert rss_peak < (64 << 20), (rss_peak, len(frame))                              # no host copy of the compressed entry, let alone the output
 
 
+@pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 3)])
+@pytest.mark.parametrize("in_window,out_window", [(131075, 4096), (3000, 70000), (1 << 20, 1 << 16), (70001, 1 << 22)])
+def test_stream_read_in_bounded_steps_with_odd_windows(Z, method, level, in_window, out_window):
+    """The bounded block-parallel steps behind zpack_read_file_stream with windows that do not fit their grain: an output window far
+    smaller than a step's output (the reader pulls no input while output waits), an input window smaller than a block (the host keeps
+    the bytes until blocks are complete), windows larger than a step: every byte, the verdict with the last one."""
+    size = (5 << 20) + 12345
+    plain = dg.fill(dg.TEXT, 31, 7, size)
+    frame = np.frombuffer(dg.compress(method, level, plain), dtype=np.uint8)
+    arc = zpk.assemble([frame.tobytes()], [("odd", 10, len(frame), size, dg.xxh3(plain), method)])
+    sink = np.zeros(size, dtype=np.uint8)
+    rc, r, keep = Z.open_memory(arc)
+    assert rc == 0
+    rc, first_out_in, rss_peak, got = _stream_entry(Z, r, 0, in_window, out_window, sink)
+    Z.lib.zpack_close_reader(C.byref(r))
+    assert rc == 0 and got == size and np.array_equal(sink, plain), (rc, got)
+
+
 @pytest.mark.parametrize("method,level", [(METHOD_LZ4, 0), (METHOD_ZSTD, 3), (METHOD_NONE, 0)])
 @pytest.mark.parametrize("claimed", [(1 << 64) - 1, 0xAAAAAAAAAAAAA000, (1 << 64) - 64, 1 << 47])
 def test_stream_read_survives_lying_entry_sizes(Z, method, level, claimed):
